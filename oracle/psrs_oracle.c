@@ -439,17 +439,20 @@ int oracle_evalmc(psrs_t *p, int64_t n_episodes, const double *pi, int64_t pi_ro
 /* Encoders                                                            */
 /* ------------------------------------------------------------------ */
 /* CartpoleBoxEncoder.get_box  (offsim4rl/encoders/heuristic.py:19-60).
- * Observations are promoted to double before the compares, as Python does
- * with np.float32 scalars against float literals. */
-int64_t oracle_cartpole_box(double x, double x_dot, double theta, double theta_dot) {
-    const double ONE = 0.0174532, SIX = 0.1047192, TWELVE = 0.2094384, FIFTY = 0.87266;
+ * The observations are float32 rows, so every `x < literal` in the reference is a
+ * np.float32-vs-Python-float comparison.  Under NumPy 2 (NEP 50, the NumPy the golden
+ * vectors were produced with) the literal is rounded to float32 and the compare is done in
+ * float32; NumPy 1.x compared in float64.  The two differ only for observations exactly equal
+ * to a float32-rounded threshold.  The oracle follows the pinned (NumPy 2) behaviour. */
+int64_t oracle_cartpole_box(float x, float x_dot, float theta, float theta_dot) {
+    const float ONE = (float)0.0174532, SIX = (float)0.1047192, TWELVE = (float)0.2094384, FIFTY = (float)0.87266;
     int64_t box;
-    if (x < -2.4 || x > 2.4 || theta < -TWELVE || theta > TWELVE) return -1;
-    if (x < -0.8) box = 0;
-    else if (x < 0.8) box = 1;
+    if (x < (float)-2.4 || x > (float)2.4 || theta < -TWELVE || theta > TWELVE) return -1;
+    if (x < (float)-0.8) box = 0;
+    else if (x < (float)0.8) box = 1;
     else box = 2;
-    if (x_dot < -0.5) {
-    } else if (x_dot < 0.5) box += 3;
+    if (x_dot < (float)-0.5) {
+    } else if (x_dot < (float)0.5) box += 3;
     else box += 6;
     if (theta < -SIX) {
     } else if (theta < -ONE) box += 9;

@@ -162,6 +162,8 @@ def psrs_fixture(name, inp, seeds, pi=None, gamma=0.99, p_new_step=None, reject_
                 h.env.rejection_sampling_rng = np.random.default_rng(seed=s)
                 init = init_order(inp["t0"], shared_shuffle_seed)
             keys, off, q = h.orders()
+            # the reference's init_queue holds (z, s) pairs; they must be the z of our index shuffle
+            assert [e[0] for e in h.env.init_queue] == [int(inp["z"][i]) for i in init]
             if store_orders and proto == ("step" if p_new_step is not None else "mc"):
                 out[f"s{s}_keys"], out[f"s{s}_off"], out[f"s{s}_queue"], out[f"s{s}_init"] = keys, off, q, init
             if proto == "step":
