@@ -1,0 +1,185 @@
+/*
+ * offsim.h -- C ABI of the MI355X-native Per-State Rejection Sampling (PSRS) engine.
+ *
+ * Drop-in boundary for the replay-loop hot path of microsoft/rl-offline-simulation (offsim4rl).
+ * The reference has no FFI of its own (it is pure Python); each entry point below names the
+ * reference function it replaces (paths relative to the reference checkout).  A maintainer binds
+ * these with ctypes -- see INTEGRATION.md for the stub that goes into
+ * offsim4rl/evaluators/per_state_rejection.py.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr() of a contiguous
+ *     ROCm tensor) unless the name ends in _host.  The library never frees caller memory and never
+ *     allocates what it returns; scratch is passed in.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).  All
+ *     calls are asynchronous with respect to the host and safe to capture in a hipGraph.
+ *   - Return value: 0 = OFFSIM_OK, negative = error; offsim_last_error() gives the message for the
+ *     calling thread.  Nothing throws across the boundary.  No Python state; call with the GIL released.
+ *   - "slot" = z - z_base: latent states are stored as non-negative slots so that z = -1
+ *     (CartpoleBoxEncoder failure code, offsim4rl/encoders/heuristic.py:23-24) is a legal queue key.
+ */
+#ifndef OFFSIM_H
+#define OFFSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFFSIM_OK 0
+#define OFFSIM_EINVAL (-1)   /* bad argument */
+#define OFFSIM_EHIP (-2)     /* HIP runtime error (launch, no device, ...) */
+#define OFFSIM_EUNSUPPORTED (-3)
+
+/* dtype tags */
+#define OFFSIM_F32 0
+#define OFFSIM_F64 1
+#define OFFSIM_F16 2
+
+/* accept/reject rule (offsim4rl/evaluators/per_state_rejection.py:97 `_reject` hook) */
+#define OFFSIM_REJECT_DEFAULT 0 /* psrs.py:53-57  u > p_new[a]/p_log[a]/max(p_new/p_log)          */
+#define OFFSIM_REJECT_NEVER 1   /* trivial_baselines.py:8-10,22-24  accept head, no RNG draw       */
+
+/* arithmetic of the default rule, following NumPy promotion */
+#define OFFSIM_PROB_F64 0 /* p_new f64 (p_log widened exactly): divisions and compare in f64      */
+#define OFFSIM_PROB_F32 1 /* p_new f32 and p_log f32: divisions in f32, u rounded to f32          */
+
+/* per-rollout status written by offsim_eval_mc / offsim_step_batch */
+#define OFFSIM_ST_OK 0          /* step accepted / episode cap reached                              */
+#define OFFSIM_ST_EXHAUSTED 1   /* PSRS.step returned (None,)*4: queue of current state empty       */
+#define OFFSIM_ST_NO_INIT 2     /* PSRS.reset returned None: init queue empty                       */
+#define OFFSIM_ST_KEYERROR 3    /* current state never occurs as a from-state (psrs.py:44)          */
+#define OFFSIM_ST_INACTIVE 4    /* rollout had no current state (s is None); nothing done           */
+
+/* The logged-transition table, SoA, rows physically grouped by from-state (CSR).  Built by
+ * offsim_group_by_state + offsim_table_gather from the OfflineDataset.experience arrays
+ * (offsim4rl/data.py:46-58) and the encoder output (per_state_rejection.py:29-35).
+ * Replaces PSRS._calculate_latent_state + the sorted/groupby of reset_sampler (psrs.py:16-17,26). */
+typedef struct offsim_table {
+    int64_t N;              /* logged transitions                                               */
+    int32_t n_slots;        /* states are slots 0..n_slots-1                                    */
+    int32_t nA;             /* actions                                                          */
+    int32_t plog_dtype;     /* OFFSIM_F32 | OFFSIM_F64 | OFFSIM_F16                             */
+    int32_t r_dtype;        /* OFFSIM_F32 | OFFSIM_F64                                          */
+    const uint32_t *seg_off;  /* [n_slots+1] first grouped row of each state                    */
+    const void *p_log;        /* [N,nA] logging-policy probabilities (hot candidate stream)     */
+    const int32_t *a;         /* [N]    logged action            (hot candidate stream)         */
+    const void *r;            /* [N]    reward                   (accept-only stream)           */
+    const int32_t *z_next;    /* [N]    slot of the next state   (accept-only stream)           */
+    const uint8_t *done;      /* [N]    terminal flag            (accept-only stream)           */
+    const int32_t *orig_idx;  /* [N]    row in the caller's buffer (for accepted-index reports) */
+    int64_t N0;               /* rows with step == 0 (all rows if `steps` is absent, data.py:72) */
+    const int32_t *init_slot; /* [N0]   slot of the k-th initial row, buffer order (psrs.py:22) */
+    const int32_t *init_orig; /* [N0]   its row in the caller's buffer                          */
+} offsim_table;
+
+/* State of R independent simulated rollouts (one PSRS env each).  Owned by the caller. */
+typedef struct offsim_rollouts {
+    int32_t R;
+    uint64_t *rng;          /* [R,4] rejection stream: PCG64 state hi, lo, inc hi, lo (psrs.py:20) */
+    uint32_t *cursor;       /* [R,n_slots] candidates popped so far from each state's queue       */
+    uint32_t *init_cursor;  /* [R] initial states popped so far (psrs.py:36)                      */
+    int32_t *cur_slot;      /* [R] current state slot, -1 = none (self.s is None)                 */
+    const uint32_t *perm;   /* queue order: perm[r*perm_stride + seg_off[s] + k] = grouped row of
+                               the k-th element of state s's queue.  perm_stride = N for per-rollout
+                               shuffles, 0 for one order shared by all rollouts; NULL = table order */
+    int64_t perm_stride;
+    const uint32_t *init_perm; /* init_perm[r*init_stride + k] = index into init_slot/init_orig   */
+    int64_t init_stride;
+} offsim_rollouts;
+
+const char *offsim_last_error(void);
+int offsim_version(void);
+/* number of HIP devices visible, or a negative error; never initialises a context */
+int offsim_device_count(void);
+
+/* ---- table construction (a1, a6, a12) -------------------------------------------------------- */
+
+/* Stable group-by of rows by slot: order[g] = original row of grouped row g, seg_off = CSR offsets.
+ * == sorted(buffer, key=z) + groupby of psrs.py:26 (buffer order inside a state).
+ * scratch: at least offsim_group_scratch_bytes(N, n_slots) bytes. */
+int64_t offsim_group_scratch_bytes(int64_t N, int32_t n_slots);
+int offsim_group_by_state(const int32_t *slot, int64_t N, int32_t n_slots, uint32_t *seg_off /*[n_slots+1]*/,
+                          int32_t *order /*[N]*/, void *scratch, void *stream);
+
+/* Gathers the caller's row-major arrays into the grouped SoA layout: dst[g] = src[order[g]].
+ * elem_bytes in {1,2,4,8,...}; row_elems = elements per row (nA for p_log). */
+int offsim_gather_rows(const void *src, const int32_t *order, int64_t N, int32_t row_bytes, void *dst, void *stream);
+
+/* ---- sampler (a2, a3) ------------------------------------------------------------------------ */
+
+/* np.random.default_rng(seed) for R seeds: SeedSequence -> PCG64 (psrs.py:20).  seeds, out on device. */
+int offsim_seed_streams(const uint64_t *seeds, int32_t R, uint64_t *rng_out /*[R,4]*/, void *stream);
+
+/* PSRS.reset_sampler(seed) queue shuffles (psrs.py:22-23,29-30) for n_perm seeds at once:
+ * every state's queue and the init queue get a backward Fisher-Yates driven by a FRESH
+ * default_rng(seed).  perm_out [n_perm,N] holds grouped rows, init_perm_out [n_perm,N0] indices. */
+int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out,
+                          uint32_t *init_perm_out, void *stream);
+
+/* PSRS.reset() (psrs.py:32-37) for every rollout with mask[r] != 0 (mask NULL = all): pops the
+ * init queue, sets cur_slot; out_init_row[r] = caller-buffer row of the initial state or -1 (None). */
+int offsim_env_reset(const offsim_table *t, offsim_rollouts *ro, const uint8_t *mask, int32_t *out_init_row,
+                     void *stream);
+
+/* ---- the replay loop (a4, a5, a7, a8, a9) ---------------------------------------------------- */
+
+/* One PSRS.step(p_new) (psrs.py:39-51) per rollout with a current state.
+ * p_new [R,nA] f64 (prob_mode F64) or f32 (prob_mode F32).
+ * out_row[r]   caller-buffer row of the accepted transition, or -1
+ * out_status[r] OFFSIM_ST_*;  out_popped[r] candidates consumed by this call.
+ * max_pop > 0 caps the candidates popped (max_pop = 1 with OFFSIM_REJECT_NEVER is the "pop one
+ * candidate for a Python-side _reject override" primitive); advance = 0 leaves cur_slot unchanged. */
+int offsim_step_batch(const offsim_table *t, offsim_rollouts *ro, const void *p_new, int32_t prob_mode,
+                      int32_t reject_mode, int32_t advance, int32_t *out_row, int32_t *out_status,
+                      uint32_t *out_popped, void *stream);
+
+/* Sets the current state of masked rollouts (used after a Python-side accept): cur_slot[r] = slot[r]. */
+int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream);
+
+/* evalMC_psrs(env, n_episodes, pi, gamma) (psrs.py:241-271) for all rollouts in one launch.
+ * pi [n_slots,nA] (row s = policy in state slot s), same dtype rule as p_new.
+ * gamma_pow [n_gamma_pow] f64 holds gamma**t as the host computes it (Python float ** int); the
+ *   device falls back to pow() beyond it.
+ * out_sum_g[r] sum of completed episodes' returns (episode order), out_n_ep[r] their number,
+ * out_steps[r] accepted steps, out_cand[r] candidates examined, out_n_len[r] entries of `lengths`
+ * (n_ep or n_ep+1, psrs.py:265), out_status[r] why the rollout stopped.
+ * Optional (NULL to skip): ep_g [R,ep_cap] f64, ep_len [R,ep_cap+1] i32 per-episode values;
+ * trace_row [R,trace_cap] i32 accepted caller-buffer rows, trace_pop [R,trace_cap] u32 candidates per step. */
+typedef struct offsim_evalmc_out {
+    double *sum_g;
+    int64_t *n_ep;
+    int64_t *steps;
+    int64_t *cand;
+    int64_t *n_len;
+    int32_t *status;
+    double *ep_g;
+    int32_t *ep_len;
+    int64_t ep_cap;
+    int32_t *trace_row;
+    uint32_t *trace_pop;
+    int64_t trace_cap;
+} offsim_evalmc_out;
+
+int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, int32_t prob_mode, int32_t reject_mode,
+                   double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
+                   const offsim_evalmc_out *out, void *stream);
+
+/* ---- encoders (a10, a11) --------------------------------------------------------------------- */
+
+/* CartpoleBoxEncoder.encode (offsim4rl/encoders/heuristic.py:19-71): obs [N,4] f32 -> z [N] i32 in -1..161 */
+int offsim_encode_box(const float *obs, int64_t N, int32_t *out_z, void *stream);
+
+/* HOMEREncoder.encode (offsim4rl/encoders/homer.py:159-168) over EncoderModel.obs_encoder
+ * (offsim4rl/encoders/models.py:15-19): z = argmax(W2 leaky_relu(W1 x + b1, 0.01) + b2).
+ * x [N,dO] f32 (x_dtype OFFSIM_F32) or f16; W1 [H,dO], b1 [H], W2 [nZ,H], b2 [nZ] f32 (state_dict layout).
+ * out_logits may be NULL. */
+int offsim_encode_mlp(const void *x, int32_t x_dtype, int64_t N, int32_t dO, const float *W1, const float *b1,
+                      int32_t H, const float *W2, const float *b2, int32_t nZ, int32_t *out_z, float *out_logits,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFFSIM_H */

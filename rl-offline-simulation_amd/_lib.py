@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI in include/offsim.h (csrc/liboffsim_hip.so).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible, the product
+path raises.  torch is used only for device memory, streams and torch.distributed.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liboffsim_hip.so")
+
+OK = 0
+F32, F64, F16 = 0, 1, 2
+REJECT_DEFAULT, REJECT_NEVER = 0, 1
+PROB_F64, PROB_F32 = 0, 1
+ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE = 0, 1, 2, 3, 4
+
+_vp, _i32, _i64, _u8 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint8
+
+
+class Table(C.Structure):
+    """struct offsim_table"""
+    _fields_ = [("N", _i64), ("n_slots", _i32), ("nA", _i32), ("plog_dtype", _i32), ("r_dtype", _i32),
+                ("seg_off", _vp), ("p_log", _vp), ("a", _vp), ("r", _vp), ("z_next", _vp), ("done", _vp),
+                ("orig_idx", _vp), ("N0", _i64), ("init_slot", _vp), ("init_orig", _vp)]
+
+
+class Rollouts(C.Structure):
+    """struct offsim_rollouts"""
+    _fields_ = [("R", _i32), ("rng", _vp), ("cursor", _vp), ("init_cursor", _vp), ("cur_slot", _vp),
+                ("perm", _vp), ("perm_stride", _i64), ("init_perm", _vp), ("init_stride", _i64)]
+
+
+class EvalMCOut(C.Structure):
+    """struct offsim_evalmc_out"""
+    _fields_ = [("sum_g", _vp), ("n_ep", _vp), ("steps", _vp), ("cand", _vp), ("n_len", _vp), ("status", _vp),
+                ("ep_g", _vp), ("ep_len", _vp), ("ep_cap", _i64), ("trace_row", _vp), ("trace_pop", _vp),
+                ("trace_cap", _i64)]
+
+
+# name -> (restype, argtypes): exactly the entry points include/offsim.h declares
+SIGNATURES = {
+    "offsim_last_error": (C.c_char_p, []),
+    "offsim_version": (C.c_int, []),
+    "offsim_device_count": (C.c_int, []),
+    "offsim_group_scratch_bytes": (_i64, [_i64, _i32]),
+    "offsim_group_by_state": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "offsim_gather_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "offsim_seed_streams": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "offsim_shuffle_queues": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp, _vp]),
+    "offsim_env_reset": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _vp, _vp]),
+    "offsim_env_set_state": (C.c_int, [C.POINTER(Rollouts), _vp, _vp, _vp]),
+    "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
+                                 C.POINTER(EvalMCOut), _vp]),
+    "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class OffsimError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library and bind every symbol; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OffsimError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or rl-offline-simulation_amd/csrc/build.sh).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise OffsimError(f"offsim error {rc}: {load().offsim_last_error().decode()}")
+
+
+def require_device():
+    """Fail loudly when the HIP path cannot run (no GPU visible to torch)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise OffsimError("no HIP device visible: the PSRS engine runs only on the GPU (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """device pointer of a contiguous torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "offsim needs contiguous tensors"
+    return t.data_ptr()

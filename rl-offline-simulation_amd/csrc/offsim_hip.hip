@@ -1,0 +1,804 @@
+// offsim_hip.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/offsim.h.
+//
+// Hot path: Per-State Rejection Sampling replay loop of offsim4rl
+//   PSRS.reset_sampler / reset / step / _default_reject   offsim4rl/evaluators/psrs.py:19-57
+//   evalMC_psrs                                           offsim4rl/evaluators/psrs.py:241-271
+// Layout: logged transitions SoA in HBM, rows grouped by from-state (CSR), so the candidates of
+// one state's queue are contiguous; per-rollout queue cursors live in LDS; one wavefront (64
+// lanes) simulates one rollout and tests 64 consecutive candidates of the current queue per
+// iteration, lane k with PCG64 draw c+k (jump-ahead), __ballot picks the first accepted one.
+//
+// No CPU fallback lives here: without a HIP device every entry point returns OFFSIM_EHIP.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "offsim.h"
+#include "pcg64_dev.hpp"
+
+using namespace offsim;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) return fail(OFFSIM_EHIP, #expr ": %s", hipGetErrorString(_e)); \
+    } while (0)
+#define LAUNCH_CHECK()                                                       \
+    do {                                                                     \
+        hipError_t _e = hipGetLastError();                                   \
+        if (_e != hipSuccess) return fail(OFFSIM_EHIP, "kernel launch: %s", hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char *offsim_last_error(void) { return g_err; }
+extern "C" int offsim_version(void) { return 100; }
+extern "C" int offsim_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(OFFSIM_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// Table construction: stable group-by-state (counting sort with per-chunk histograms)
+// ------------------------------------------------------------------------------------------------
+#define GRP_CHUNK 2048  // rows ranked by one wavefront, 64 at a time, in buffer order
+
+// pass 1: hist[chunk][slot] = rows of `slot` inside the chunk
+__global__ void k_group_hist(const int32_t *__restrict__ slot, int64_t N, int32_t n_slots, uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t lds_cnt[];
+    for (int s = threadIdx.x; s < n_slots; s += blockDim.x) lds_cnt[s] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * GRP_CHUNK;
+    for (int i = threadIdx.x; i < GRP_CHUNK; i += blockDim.x) {
+        int64_t row = base + i;
+        if (row < N) atomicAdd(&lds_cnt[slot[row]], 1u);
+    }
+    __syncthreads();
+    uint32_t *h = hist + (int64_t)blockIdx.x * n_slots;
+    for (int s = threadIdx.x; s < n_slots; s += blockDim.x) h[s] = lds_cnt[s];
+}
+
+// pass 2a: per slot, exclusive scan over chunks (in place) and slot totals
+__global__ void k_group_scan_chunks(uint32_t *__restrict__ hist, int64_t n_chunks, int32_t n_slots, uint32_t *__restrict__ totals) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    uint32_t run = 0;
+    for (int64_t c = 0; c < n_chunks; c++) {
+        uint32_t v = hist[c * n_slots + s];
+        hist[c * n_slots + s] = run;
+        run += v;
+    }
+    totals[s] = run;
+}
+// pass 2b: seg_off = exclusive scan of totals (one wavefront)
+__global__ void k_group_scan_slots(const uint32_t *__restrict__ totals, int32_t n_slots, uint32_t *__restrict__ seg_off) {
+    uint32_t carry = 0;
+    int lane = threadIdx.x;
+    for (int b = 0; b < n_slots; b += WAVE) {
+        int s = b + lane;
+        uint32_t v = s < n_slots ? totals[s] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (s < n_slots) seg_off[s] = carry + inc - v;
+        carry += __shfl(inc, WAVE - 1);
+    }
+    if (lane == 0) seg_off[n_slots] = carry;
+}
+// pass 3: stable rank inside the chunk, one wavefront per chunk; order[dst] = row
+__global__ void k_group_scatter(const int32_t *__restrict__ slot, int64_t N, int32_t n_slots,
+                                const uint32_t *__restrict__ hist, const uint32_t *__restrict__ seg_off,
+                                int32_t *__restrict__ order) {
+    extern __shared__ uint32_t lds_pos_raw[];  // next grouped row of each slot for this chunk
+    volatile uint32_t *lds_pos = lds_pos_raw;    // lanes hand values to each other through it
+    const uint32_t *h = hist + (int64_t)blockIdx.x * n_slots;
+    for (int s = threadIdx.x; s < n_slots; s += WAVE) lds_pos[s] = seg_off[s] + h[s];
+    __syncthreads();
+    int lane = threadIdx.x;
+    int64_t base = (int64_t)blockIdx.x * GRP_CHUNK;
+    for (int i = 0; i < GRP_CHUNK; i += WAVE) {
+        int64_t row = base + i + lane;
+        bool valid = row < N;
+        int32_t key = valid ? slot[row] : -1;
+        uint64_t todo = __ballot(valid);
+        uint32_t dst = 0;
+        while (todo) {  // one pass per distinct key among the 64 rows
+            int leader = __ffsll((unsigned long long)todo) - 1;
+            int32_t k = __shfl(key, leader);
+            uint64_t same = __ballot(valid && key == k);
+            if (valid && key == k) {
+                uint32_t before = __popcll(same & ((1ull << lane) - 1ull));
+                dst = lds_pos[k] + before;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): reads of lds_pos[k] done before its update
+            if (lane == leader) lds_pos[k] += __popcll(same);
+            todo &= ~same;
+        }
+        if (valid) order[dst] = (int32_t)row;
+    }
+}
+
+extern "C" int64_t offsim_group_scratch_bytes(int64_t N, int32_t n_slots) {
+    int64_t n_chunks = (N + GRP_CHUNK - 1) / GRP_CHUNK;
+    if (n_chunks < 1) n_chunks = 1;
+    return (n_chunks * n_slots + n_slots) * (int64_t)sizeof(uint32_t) + 256;
+}
+
+extern "C" int offsim_group_by_state(const int32_t *slot, int64_t N, int32_t n_slots, uint32_t *seg_off, int32_t *order,
+                                     void *scratch, void *stream) {
+    if (N < 0 || n_slots <= 0 || !seg_off || !scratch) return fail(OFFSIM_EINVAL, "group_by_state: bad argument%s");
+    if ((int64_t)n_slots * 4 > 64 * 1024) return fail(OFFSIM_EUNSUPPORTED, "group_by_state: more than 16384 states%s");
+    if (N >= (1ll << 31)) return fail(OFFSIM_EUNSUPPORTED, "group_by_state: N >= 2^31%s");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t n_chunks = (N + GRP_CHUNK - 1) / GRP_CHUNK;
+    uint32_t *hist = (uint32_t *)scratch;
+    uint32_t *totals = hist + (n_chunks > 0 ? n_chunks : 1) * n_slots;
+    if (n_chunks == 0) {
+        HIP_TRY(hipMemsetAsync(seg_off, 0, sizeof(uint32_t) * (n_slots + 1), st));
+        return OFFSIM_OK;
+    }
+    size_t lds = sizeof(uint32_t) * n_slots;
+    hipLaunchKernelGGL(k_group_hist, dim3((unsigned)n_chunks), dim3(256), lds, st, slot, N, n_slots, hist);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_group_scan_chunks, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_chunks, n_slots, totals);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_group_scan_slots, dim3(1), dim3(WAVE), 0, st, totals, n_slots, seg_off);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_group_scatter, dim3((unsigned)n_chunks), dim3(WAVE), lds, st, slot, N, n_slots, hist, seg_off, order);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// dst[g] = src[order[g]] for rows of row_bytes bytes (1,2,4,8 or a multiple of 4)
+template <typename T>
+__global__ void k_gather_elem(const T *__restrict__ src, const int32_t *__restrict__ order, int64_t N, T *__restrict__ dst) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < N) dst[g] = src[order[g]];
+}
+__global__ void k_gather_words(const uint32_t *__restrict__ src, const int32_t *__restrict__ order, int64_t N, int32_t words,
+                               uint32_t *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * words) return;
+    int64_t g = i / words;
+    int32_t w = (int32_t)(i - g * words);
+    dst[i] = src[(int64_t)order[g] * words + w];
+}
+extern "C" int offsim_gather_rows(const void *src, const int32_t *order, int64_t N, int32_t row_bytes, void *dst, void *stream) {
+    if (N < 0 || row_bytes <= 0) return fail(OFFSIM_EINVAL, "gather_rows: bad argument%s");
+    if (N == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned nb = (unsigned)((N + 255) / 256);
+    if (row_bytes == 1) hipLaunchKernelGGL(k_gather_elem<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t *)src, order, N, (uint8_t *)dst);
+    else if (row_bytes == 2) hipLaunchKernelGGL(k_gather_elem<uint16_t>, dim3(nb), dim3(256), 0, st, (const uint16_t *)src, order, N, (uint16_t *)dst);
+    else if (row_bytes == 4) hipLaunchKernelGGL(k_gather_elem<uint32_t>, dim3(nb), dim3(256), 0, st, (const uint32_t *)src, order, N, (uint32_t *)dst);
+    else if (row_bytes == 8) hipLaunchKernelGGL(k_gather_elem<uint64_t>, dim3(nb), dim3(256), 0, st, (const uint64_t *)src, order, N, (uint64_t *)dst);
+    else if (row_bytes % 4 == 0) {
+        int32_t words = row_bytes / 4;
+        unsigned nbw = (unsigned)((N * words + 255) / 256);
+        hipLaunchKernelGGL(k_gather_words, dim3(nbw), dim3(256), 0, st, (const uint32_t *)src, order, N, words, (uint32_t *)dst);
+    } else if (row_bytes % 2 == 0) {
+        return fail(OFFSIM_EUNSUPPORTED, "gather_rows: row_bytes must be 1, 2 or a multiple of 4%s");
+    } else return fail(OFFSIM_EUNSUPPORTED, "gather_rows: row_bytes must be 1, 2 or a multiple of 4%s");
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampler: seeding and per-rollout queue shuffles
+// ------------------------------------------------------------------------------------------------
+__global__ void k_seed_streams(const uint64_t *__restrict__ seeds, int32_t R, uint64_t *__restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    PcgInit p = pcg_seed(seeds[r]);
+    out[4 * r + 0] = p.state.hi;
+    out[4 * r + 1] = p.state.lo;
+    out[4 * r + 2] = p.inc.hi;
+    out[4 * r + 3] = p.inc.lo;
+}
+extern "C" int offsim_seed_streams(const uint64_t *seeds, int32_t R, uint64_t *rng_out, void *stream) {
+    if (R < 0 || !seeds || !rng_out) return fail(OFFSIM_EINVAL, "seed_streams: bad argument%s");
+    if (R == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_seed_streams, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, seeds, R, rng_out);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+__global__ void k_iota_rows(uint32_t *__restrict__ out, int64_t n_cols, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) out[i] = (uint32_t)(i % n_cols);
+}
+
+// One lane per (state, rollout) chain.  Chains of one state sit in adjacent lanes, so a wavefront
+// runs 64 Fisher-Yates loops of equal length; each restarts default_rng(seed) (psrs.py:29-30).
+__global__ void k_shuffle_queues(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0,
+                                 const uint64_t *__restrict__ seeds, int32_t n_perm, uint32_t *__restrict__ perm,
+                                 uint32_t *__restrict__ init_perm) {
+    int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n_chains = (int64_t)(n_slots + 1) * n_perm;
+    if (chain >= n_chains) return;
+    int32_t s = (int32_t)(chain / n_perm);
+    int32_t r = (int32_t)(chain - (int64_t)s * n_perm);
+    uint32_t *x;
+    uint32_t n;
+    if (s < n_slots) {
+        uint32_t b = seg_off[s];
+        n = seg_off[s + 1] - b;
+        x = perm + (int64_t)r * N + b;
+    } else {  // the init queue (psrs.py:22-23)
+        n = (uint32_t)N0;
+        x = init_perm + (int64_t)r * N0;
+    }
+    if (n < 2) return;
+    PcgSeq g;
+    g.init(pcg_seed(seeds[r]));
+    for (uint32_t i = n - 1; i >= 1; i--) {
+        uint32_t j = g.interval32(i);
+        uint32_t xi = x[i], xj = x[j];
+        x[i] = xj;
+        x[j] = xi;
+    }
+}
+
+extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out,
+                                     uint32_t *init_perm_out, void *stream) {
+    if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");
+    if (n_perm == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // start from table order: perm[r][g] = g, init_perm[r][k] = k
+    if (t->N > 0) {
+        int64_t total = t->N * n_perm;
+        unsigned nb = (unsigned)((total + 1023) / 1024 > 16384 ? 16384 : (total + 1023) / 1024);
+        hipLaunchKernelGGL(k_iota_rows, dim3(nb), dim3(256), 0, st, perm_out, t->N, total);
+        LAUNCH_CHECK();
+    }
+    if (t->N0 > 0) {
+        int64_t total = t->N0 * n_perm;
+        unsigned nb = (unsigned)((total + 1023) / 1024 > 16384 ? 16384 : (total + 1023) / 1024);
+        hipLaunchKernelGGL(k_iota_rows, dim3(nb), dim3(256), 0, st, init_perm_out, t->N0, total);
+        LAUNCH_CHECK();
+    }
+    int64_t n_chains = (int64_t)(t->n_slots + 1) * n_perm;
+    hipLaunchKernelGGL(k_shuffle_queues, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, st, t->seg_off, t->n_slots,
+                       t->N, t->N0, seeds, n_perm, perm_out, init_perm_out);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// env reset / set_state
+// ------------------------------------------------------------------------------------------------
+__global__ void k_env_reset(offsim_table t, offsim_rollouts ro, const uint8_t *__restrict__ mask, int32_t *__restrict__ out_row) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ro.R) return;
+    if (mask && !mask[r]) return;
+    uint32_t ic = ro.init_cursor[r];
+    if ((int64_t)ic >= t.N0) {  // psrs.py:33-35: self.s = None
+        ro.cur_slot[r] = -1;
+        if (out_row) out_row[r] = -1;
+        return;
+    }
+    uint32_t k = ro.init_perm ? ro.init_perm[(int64_t)r * ro.init_stride + ic] : ic;
+    ro.init_cursor[r] = ic + 1;
+    ro.cur_slot[r] = t.init_slot[k];
+    if (out_row) out_row[r] = t.init_orig[k];
+}
+extern "C" int offsim_env_reset(const offsim_table *t, offsim_rollouts *ro, const uint8_t *mask, int32_t *out_init_row,
+                                void *stream) {
+    if (!t || !ro || ro->R < 0) return fail(OFFSIM_EINVAL, "env_reset: bad argument%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_env_reset, dim3((ro->R + 255) / 256), dim3(256), 0, (hipStream_t)stream, *t, *ro, mask, out_init_row);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+__global__ void k_env_set_state(offsim_rollouts ro, const int32_t *__restrict__ slot, const uint8_t *__restrict__ mask) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ro.R) return;
+    if (mask && !mask[r]) return;
+    ro.cur_slot[r] = slot[r];
+}
+extern "C" int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream) {
+    if (!ro || !slot || ro->R < 0) return fail(OFFSIM_EINVAL, "env_set_state: bad argument%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_env_set_state, dim3((ro->R + 255) / 256), dim3(256), 0, (hipStream_t)stream, *ro, slot, mask);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The replay loop.  One wavefront = one rollout.
+// ------------------------------------------------------------------------------------------------
+template <typename PL>
+__device__ __forceinline__ double plog_f64(const PL *p, int64_t i);
+template <>
+__device__ __forceinline__ double plog_f64<float>(const float *p, int64_t i) { return (double)p[i]; }
+template <>
+__device__ __forceinline__ double plog_f64<double>(const double *p, int64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ double plog_f64<__half>(const __half *p, int64_t i) { return (double)__half2float(p[i]); }
+
+// psrs.py:53-57 for one candidate.  k53 = 53-bit draw, u = k53 * 2**-53.
+// F64: divisions and comparison in double (p_log widened exactly).
+template <typename PL>
+__device__ __forceinline__ bool rejects_f64(const PL *__restrict__ plog, int64_t g, int a, const double *pnew, int nA, uint64_t k53) {
+    double M = -__builtin_inf();
+    bool nan = false;
+    for (int k = 0; k < nA; k++) {
+        double q = pnew[k] / plog_f64<PL>(plog, g * nA + k);
+        nan |= (q != q);
+        M = q > M ? q : M;
+    }
+    if (nan) M = __builtin_nan("");  // ndarray.max() propagates NaN
+    double thr = pnew[a] / plog_f64<PL>(plog, g * nA + a) / M;
+    double u = (double)k53 * (1.0 / 9007199254740992.0);
+    return u > thr;
+}
+// F32: p_new and p_log both float32 -> NumPy divides in float32 and (NumPy 2 / torch 0-d) rounds u to float32.
+__device__ __forceinline__ bool rejects_f32(const float *__restrict__ plog, int64_t g, int a, const float *pnew, int nA, uint64_t k53) {
+    float M = -__builtin_inff();
+    bool nan = false;
+    for (int k = 0; k < nA; k++) {
+        float q = pnew[k] / plog[g * nA + k];
+        nan |= (q != q);
+        M = q > M ? q : M;
+    }
+    if (nan) M = __builtin_nanf("");
+    float thr = pnew[a] / plog[g * nA + a] / M;
+    double u = (double)k53 * (1.0 / 9007199254740992.0);
+    return (float)u > thr;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+struct StepResult {
+    int status;       // OFFSIM_ST_OK (accepted) | EXHAUSTED | KEYERROR
+    uint32_t popped;  // candidates consumed
+    int32_t g;        // accepted grouped row
+    int32_t z_next;
+    double r;
+    bool done;
+};
+
+// Per-wave jump table in LDS: entry d (1..64) advances the rollout's PCG64 stream by d draws.
+struct WaveRng {
+    U128 lane_state;  // state that yields draw (c + lane)
+    Jump *table;      // LDS, 65 entries
+};
+
+// One PSRS.step (psrs.py:39-51).  All arguments wave-uniform except what lanes load.
+// PROB = double (F64 mode, any p_log type) or float (F32 mode, p_log float).
+template <typename PL, typename PROB>
+__device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uint32_t *__restrict__ seg_off,
+                                                 const uint32_t *__restrict__ perm_row, int slot, uint32_t *cursor,
+                                                 const PROB *pnew, int reject_mode, uint32_t max_pop, WaveRng &rng,
+                                                 uint64_t &consumed) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    StepResult res;
+    res.popped = 0;
+    res.g = -1;
+    res.z_next = -1;
+    res.r = 0.0;
+    res.done = false;
+    if (slot < 0 || slot >= t.n_slots) {
+        res.status = OFFSIM_ST_KEYERROR;
+        return res;
+    }
+    const uint32_t beg = seg_off[slot];
+    const uint32_t len = seg_off[slot + 1] - beg;
+    if (len == 0) {  // z never occurs as a from-state: self.queues[z] raises KeyError (psrs.py:44)
+        res.status = OFFSIM_ST_KEYERROR;
+        return res;
+    }
+    uint32_t cur = cursor[slot];
+    const PL *plog = (const PL *)t.p_log;
+    const int nA = t.nA;
+    for (;;) {
+        uint32_t rem = len - cur;
+        if (rem == 0 || (max_pop && res.popped >= max_pop)) {  // psrs.py:44-45
+            res.status = OFFSIM_ST_EXHAUSTED;
+            break;
+        }
+        uint32_t nv = rem < WAVE ? rem : WAVE;
+        if (reject_mode == OFFSIM_REJECT_NEVER) nv = 1;
+        if (max_pop && nv > max_pop - res.popped) nv = max_pop - res.popped;
+        const bool valid = (uint32_t)lane < nv;
+        uint32_t g = beg + cur + (valid ? lane : 0);
+        if (perm_row) g = perm_row[g];
+        // candidate stream (p_log row, a) and, speculatively, the accept-only stream
+        const int a = t.a[g];
+        const int32_t zn = t.z_next[g];
+        const uint8_t dn = t.done[g];
+        const double rv = t.r_dtype == OFFSIM_F64 ? ((const double *)t.r)[g] : (double)((const float *)t.r)[g];
+        bool acc;
+        if (reject_mode == OFFSIM_REJECT_NEVER) {
+            acc = valid;
+        } else {
+            uint64_t k53 = pcg_output(rng.lane_state) >> 11;
+            bool rej;
+            if constexpr (sizeof(PROB) == 4) rej = rejects_f32((const float *)plog, (int64_t)g, a, (const float *)pnew, nA, k53);
+            else rej = rejects_f64<PL>(plog, (int64_t)g, a, (const double *)pnew, nA, k53);
+            acc = valid && !rej;
+        }
+        uint64_t m = __ballot(acc);
+        uint32_t d;  // candidates consumed by this iteration
+        int f = -1;
+        if (m == 0) d = nv;
+        else {
+            f = __ffsll((unsigned long long)m) - 1;
+            d = (uint32_t)f + 1;
+        }
+        cur += d;
+        res.popped += d;
+        if (reject_mode != OFFSIM_REJECT_NEVER) {  // every examined candidate consumed exactly one draw (psrs.py:56)
+            Jump j = rng.table[d];
+            rng.lane_state = pcg_apply(j, rng.lane_state);
+            consumed += d;
+        }
+        if (f >= 0) {
+            res.status = OFFSIM_ST_OK;
+            res.g = __builtin_amdgcn_readlane((int)g, f);
+            res.z_next = __builtin_amdgcn_readlane(zn, f);
+            res.done = __builtin_amdgcn_readlane((int)dn, f) != 0;
+            res.r = readlane_f64(rv, f);
+            break;
+        }
+    }
+    cursor[slot] = cur;
+    return res;
+}
+
+// Fill the per-wave jump table and position lane k on draw k of the stream that starts at `base`.
+__device__ __forceinline__ void wave_rng_init(WaveRng &rng, Jump *table, U128 base, U128 inc) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    rng.table = table;
+    Jump mine = pcg_jump(inc, (uint64_t)lane + 1);
+    table[lane + 1] = mine;
+    if (lane == 0) {
+        Jump id;
+        id.mult = u128(0, 1);
+        id.plus = u128(0, 0);
+        table[0] = id;
+    }
+    rng.lane_state = pcg_apply(mine, base);  // draw k is the output after k+1 steps
+}
+
+// ---- step_batch: one PSRS.step per rollout, cursors stay in global memory ----
+template <typename PL, typename PROB>
+__global__ void __launch_bounds__(256) k_step_batch(offsim_table t, offsim_rollouts ro, const PROB *__restrict__ p_new,
+                                                    int reject_mode, int advance, uint32_t max_pop,
+                                                    int32_t *__restrict__ out_row, int32_t *__restrict__ out_status,
+                                                    uint32_t *__restrict__ out_popped) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int r = blockIdx.x * (blockDim.x / WAVE) + wave;
+    if (r >= ro.R) return;
+    int slot = ro.cur_slot[r];
+    if (slot < 0) {
+        if (lane == 0) {
+            if (out_row) out_row[r] = -1;
+            if (out_status) out_status[r] = OFFSIM_ST_INACTIVE;
+            if (out_popped) out_popped[r] = 0;
+        }
+        return;
+    }
+    Jump *table = (Jump *)lds_raw + wave * (WAVE + 1);
+    WaveRng rng;
+    U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+    U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+    if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc);
+    uint64_t consumed = 0;
+    const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
+    StepResult s = psrs_step<PL, PROB>(t, t.seg_off, perm_row, slot, ro.cursor + (int64_t)r * t.n_slots,
+                                       p_new + (int64_t)r * t.nA, reject_mode, max_pop, rng, consumed);
+    if (lane == 0) {
+        if (consumed) {
+            U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
+            ro.rng[4 * r + 0] = nb.hi;
+            ro.rng[4 * r + 1] = nb.lo;
+        }
+        if (s.status == OFFSIM_ST_OK && advance) ro.cur_slot[r] = s.z_next;  // psrs.py:49-50
+        if (out_row) out_row[r] = s.status == OFFSIM_ST_OK ? t.orig_idx[s.g] : -1;
+        if (out_status) out_status[r] = s.status;
+        if (out_popped) out_popped[r] = s.popped;
+    }
+}
+
+// ---- eval_mc: the whole evalMC_psrs loop (psrs.py:241-271) on device, cursors in LDS ----
+template <typename PL, typename PROB>
+__global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollouts ro, const PROB *__restrict__ pi,
+                                                 int reject_mode, double gamma, const double *__restrict__ gamma_pow,
+                                                 int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int waves = blockDim.x / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int n_slots = t.n_slots, nA = t.nA;
+    // LDS carve: [jump tables][pi][seg_off][cursors per wave]
+    Jump *tables = (Jump *)lds_raw;
+    PROB *pi_lds = (PROB *)(tables + waves * (WAVE + 1));
+    uint32_t *seg_lds = (uint32_t *)(pi_lds + (size_t)n_slots * nA);
+    uint32_t *cur_lds = seg_lds + (n_slots + 1) + (size_t)wave * n_slots;
+    for (int i = threadIdx.x; i < n_slots * nA; i += blockDim.x) pi_lds[i] = pi[i];
+    for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg_lds[i] = t.seg_off[i];
+    __syncthreads();
+    const int r = blockIdx.x * waves + wave;
+    if (r >= ro.R) return;
+    uint32_t *cur_glb = ro.cursor + (int64_t)r * n_slots;
+    for (int s = lane; s < n_slots; s += WAVE) cur_lds[s] = cur_glb[s];
+
+    WaveRng rng;
+    U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+    U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+    wave_rng_init(rng, tables + wave * (WAVE + 1), base, inc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): table and cursors visible to the whole wave
+
+    const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
+    const uint32_t *init_row = ro.init_perm ? ro.init_perm + (int64_t)r * ro.init_stride : nullptr;
+    uint32_t ic = ro.init_cursor[r];
+    int slot = ro.cur_slot[r];
+    int64_t ep = 0, n_len = 0, steps = 0, cand = 0;
+    uint64_t consumed = 0;
+    double sum_g = 0.0;
+    int status = OFFSIM_ST_OK;
+    bool terminate = false;
+    while (ep < max_episodes && !terminate) {
+        // env.reset()  (psrs.py:32-37, :249-252)
+        if ((int64_t)ic >= t.N0) {
+            status = OFFSIM_ST_NO_INIT;
+            slot = -1;
+            break;
+        }
+        uint32_t k = init_row ? init_row[ic] : ic;
+        ic++;
+        slot = t.init_slot[k];
+        double G = 0.0;
+        int64_t tt = 0;
+        bool done = false;
+        while (!done) {
+            const double gp = tt < n_gamma_pow ? gamma_pow[tt] : pow(gamma, (double)tt);  // issued ahead of the step
+            StepResult s = psrs_step<PL, PROB>(t, seg_lds, perm_row, slot, cur_lds, pi_lds + (size_t)slot * nA, reject_mode, 0u,
+                                               rng, consumed);
+            cand += s.popped;
+            if (s.status != OFFSIM_ST_OK) {  // :257-259 (None) or KeyError
+                status = s.status;
+                terminate = true;
+                break;
+            }
+            if (lane == 0) {
+                if (out.trace_row && steps < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + steps] = t.orig_idx[s.g];
+                if (out.trace_pop && steps < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + steps] = s.popped;
+            }
+            G = G + gp * s.r;  // :262 (no FMA contraction: built with -ffp-contract=off)
+            tt++;
+            steps++;
+            slot = s.z_next;
+            done = s.done;
+        }
+        if (status == OFFSIM_ST_KEYERROR) break;  // the reference raises out of evalMC_psrs here
+        if (lane == 0 && out.ep_len && n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)tt;
+        n_len++;  // :265 lengths.append(t) always
+        if (done) {  // :266-269
+            if (lane == 0 && out.ep_g && ep < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep] = G;
+            sum_g += G;
+            ep++;
+        }
+    }
+    // write back the env state so that a later call continues where this one stopped
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int s = lane; s < n_slots; s += WAVE) cur_glb[s] = cur_lds[s];
+    if (lane == 0) {
+        ro.init_cursor[r] = ic;
+        ro.cur_slot[r] = slot;
+        if (consumed) {
+            U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
+            ro.rng[4 * r + 0] = nb.hi;
+            ro.rng[4 * r + 1] = nb.lo;
+        }
+        out.sum_g[r] = sum_g;
+        out.n_ep[r] = ep;
+        out.steps[r] = steps;
+        out.cand[r] = cand;
+        out.n_len[r] = n_len;
+        out.status[r] = status;
+    }
+}
+
+static size_t evalmc_lds_bytes(int waves, int n_slots, int nA, size_t prob_bytes) {
+    return (size_t)waves * (WAVE + 1) * sizeof(Jump) + (size_t)n_slots * nA * prob_bytes + (size_t)(n_slots + 1) * 4 +
+           (size_t)waves * n_slots * 4;
+}
+
+static int check_table(const offsim_table *t) {
+    if (!t) return fail(OFFSIM_EINVAL, "table is NULL%s");
+    if (t->N < 0 || t->n_slots <= 0 || t->nA <= 0) return fail(OFFSIM_EINVAL, "table: bad N / n_slots / nA%s");
+    if (t->N > 0 && (!t->seg_off || !t->p_log || !t->a || !t->r || !t->z_next || !t->done || !t->orig_idx))
+        return fail(OFFSIM_EINVAL, "table: NULL column%s");
+    if (t->plog_dtype != OFFSIM_F32 && t->plog_dtype != OFFSIM_F64 && t->plog_dtype != OFFSIM_F16)
+        return fail(OFFSIM_EINVAL, "table: bad plog_dtype%s");
+    if (t->r_dtype != OFFSIM_F32 && t->r_dtype != OFFSIM_F64) return fail(OFFSIM_EINVAL, "table: bad r_dtype%s");
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_step_batch(const offsim_table *t, offsim_rollouts *ro, const void *p_new, int32_t prob_mode,
+                                 int32_t reject_mode, int32_t advance, int32_t *out_row, int32_t *out_status,
+                                 uint32_t *out_popped, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !p_new) return fail(OFFSIM_EINVAL, "step_batch: bad argument%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    if (prob_mode == OFFSIM_PROB_F32 && t->plog_dtype != OFFSIM_F32)
+        return fail(OFFSIM_EINVAL, "step_batch: OFFSIM_PROB_F32 needs an f32 p_log%s");
+    hipStream_t st = (hipStream_t)stream;
+    const int waves = 4;
+    dim3 grid((ro->R + waves - 1) / waves), block(waves * WAVE);
+    size_t lds = (size_t)waves * (WAVE + 1) * sizeof(Jump);
+    uint32_t max_pop = 0;
+    if (advance == 0 && reject_mode == OFFSIM_REJECT_NEVER) max_pop = 1;  // "pop one candidate" primitive
+#define LAUNCH_STEP(PL, PROB)                                                                                      \
+    hipLaunchKernelGGL((k_step_batch<PL, PROB>), grid, block, lds, st, *t, *ro, (const PROB *)p_new, reject_mode, \
+                       advance, max_pop, out_row, out_status, out_popped)
+    if (prob_mode == OFFSIM_PROB_F32) LAUNCH_STEP(float, float);
+    else if (t->plog_dtype == OFFSIM_F32) LAUNCH_STEP(float, double);
+    else if (t->plog_dtype == OFFSIM_F64) LAUNCH_STEP(double, double);
+    else LAUNCH_STEP(__half, double);
+#undef LAUNCH_STEP
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, int32_t prob_mode,
+                              int32_t reject_mode, double gamma, const double *gamma_pow, int64_t n_gamma_pow,
+                              int64_t max_episodes, const offsim_evalmc_out *out, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !pi || !out) return fail(OFFSIM_EINVAL, "eval_mc: bad argument%s");
+    if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
+        return fail(OFFSIM_EINVAL, "eval_mc: required output is NULL%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    if (prob_mode == OFFSIM_PROB_F32 && t->plog_dtype != OFFSIM_F32)
+        return fail(OFFSIM_EINVAL, "eval_mc: OFFSIM_PROB_F32 needs an f32 p_log%s");
+    if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc: gamma_pow is NULL%s");
+    hipStream_t st = (hipStream_t)stream;
+    size_t pb = prob_mode == OFFSIM_PROB_F32 ? 4 : 8;
+    int waves = 4;
+    while (waves > 1 && evalmc_lds_bytes(waves, t->n_slots, t->nA, pb) > 64 * 1024) waves >>= 1;
+    size_t lds = evalmc_lds_bytes(waves, t->n_slots, t->nA, pb);
+    if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "eval_mc: per-state cursors and policy exceed 160 KiB of LDS%s");
+    dim3 grid((ro->R + waves - 1) / waves), block(waves * WAVE);
+#define LAUNCH_MC(PL, PROB)                                                                                          \
+    do {                                                                                                             \
+        if (lds > 64 * 1024)                                                                                         \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, PROB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_eval_mc<PL, PROB>), grid, block, lds, st, *t, *ro, (const PROB *)pi, reject_mode, gamma, \
+                           gamma_pow, n_gamma_pow, max_episodes, *out);                                              \
+    } while (0)
+    if (prob_mode == OFFSIM_PROB_F32) LAUNCH_MC(float, float);
+    else if (t->plog_dtype == OFFSIM_F32) LAUNCH_MC(float, double);
+    else if (t->plog_dtype == OFFSIM_F64) LAUNCH_MC(double, double);
+    else LAUNCH_MC(__half, double);
+#undef LAUNCH_MC
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoders
+// ------------------------------------------------------------------------------------------------
+// CartpoleBoxEncoder.get_box (heuristic.py:19-60).  float32 observations compared against the
+// float32-rounded literals (what NumPy 2 does for np.float32 < python float; see oracle header).
+__global__ void k_encode_box(const float4 *__restrict__ obs, int64_t N, int32_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float4 o = obs[i];
+    const float ONE = 0.0174532f, SIX = 0.1047192f, TWELVE = 0.2094384f, FIFTY = 0.87266f;
+    float x = o.x, xd = o.y, th = o.z, thd = o.w;
+    int box;
+    if (x < -2.4f || x > 2.4f || th < -TWELVE || th > TWELVE) {
+        box = -1;
+    } else {
+        box = x < -0.8f ? 0 : (x < 0.8f ? 1 : 2);
+        box += xd < -0.5f ? 0 : (xd < 0.5f ? 3 : 6);
+        box += th < -SIX ? 0 : (th < -ONE ? 9 : (th < 0.f ? 18 : (th < ONE ? 27 : (th < SIX ? 36 : 45))));
+        box += thd < -FIFTY ? 0 : (thd < FIFTY ? 54 : 108);
+    }
+    out[i] = box;
+}
+extern "C" int offsim_encode_box(const float *obs, int64_t N, int32_t *out_z, void *stream) {
+    if (N < 0 || (N > 0 && (!obs || !out_z))) return fail(OFFSIM_EINVAL, "encode_box: bad argument%s");
+    if (N == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_encode_box, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)obs, N, out_z);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// HOMER obs_encoder forward + argmax, one row per lane, weights in LDS, k-ordered fmaf chains
+// (bit-identical to an f32 MFMA accumulation chain; see cdna guide "FP32-input MFMA").
+template <typename XT>
+__device__ __forceinline__ float x_f32(const XT *x, int64_t i);
+template <>
+__device__ __forceinline__ float x_f32<float>(const float *x, int64_t i) { return x[i]; }
+template <>
+__device__ __forceinline__ float x_f32<__half>(const __half *x, int64_t i) { return __half2float(x[i]); }
+
+#define MLP_MAX_H 128
+template <typename XT>
+__global__ void __launch_bounds__(256) k_encode_mlp(const XT *__restrict__ x, int64_t N, int dO, const float *__restrict__ W1,
+                                                    const float *__restrict__ b1, int H, const float *__restrict__ W2,
+                                                    const float *__restrict__ b2, int nZ, int32_t *__restrict__ out_z,
+                                                    float *__restrict__ out_logits) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float *w1 = (float *)lds_raw;  // [H][dO]
+    float *bb1 = w1 + H * dO;      // [H]
+    float *w2 = bb1 + H;           // [nZ][H]
+    float *bb2 = w2 + nZ * H;      // [nZ]
+    for (int i = threadIdx.x; i < H * dO; i += blockDim.x) w1[i] = W1[i];
+    for (int i = threadIdx.x; i < H; i += blockDim.x) bb1[i] = b1[i];
+    for (int i = threadIdx.x; i < nZ * H; i += blockDim.x) w2[i] = W2[i];
+    for (int i = threadIdx.x; i < nZ; i += blockDim.x) bb2[i] = b2[i];
+    __syncthreads();
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < N; row += stride) {
+        float h[MLP_MAX_H];
+#pragma unroll 4
+        for (int j = 0; j < H; j++) {
+            float acc = 0.f;
+            for (int k = 0; k < dO; k++) acc = fmaf(x_f32<XT>(x, row * dO + k), w1[j * dO + k], acc);
+            acc += bb1[j];
+            h[j] = acc > 0.f ? acc : 0.01f * acc;  // LeakyReLU(0.01)
+        }
+        int best = 0;
+        float bv = -__builtin_inff();
+        for (int c = 0; c < nZ; c++) {
+            float acc = 0.f;
+            for (int k = 0; k < H; k++) acc = fmaf(h[k], w2[c * H + k], acc);
+            acc += bb2[c];
+            if (out_logits) out_logits[row * nZ + c] = acc;
+            if (acc > bv) {  // first maximal index, as torch.max(dim=1)
+                bv = acc;
+                best = c;
+            }
+        }
+        out_z[row] = best;
+    }
+}
+extern "C" int offsim_encode_mlp(const void *x, int32_t x_dtype, int64_t N, int32_t dO, const float *W1, const float *b1,
+                                 int32_t H, const float *W2, const float *b2, int32_t nZ, int32_t *out_z, float *out_logits,
+                                 void *stream) {
+    if (N < 0 || dO <= 0 || H <= 0 || nZ <= 0 || !W1 || !b1 || !W2 || !b2) return fail(OFFSIM_EINVAL, "encode_mlp: bad argument%s");
+    if (H > MLP_MAX_H) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: hidden size > 128%s");
+    if (N == 0) return OFFSIM_OK;
+    size_t lds = sizeof(float) * ((size_t)H * dO + H + (size_t)nZ * H + nZ);
+    if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: weights exceed LDS%s");
+    unsigned nb = (unsigned)((N + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == OFFSIM_F32) {
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_encode_mlp<float>, dim3(nb), dim3(256), lds, st, (const float *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits);
+    } else if (x_dtype == OFFSIM_F16) {
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_encode_mlp<__half>, dim3(nb), dim3(256), lds, st, (const __half *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits);
+    } else return fail(OFFSIM_EINVAL, "encode_mlp: x_dtype must be OFFSIM_F32 or OFFSIM_F16%s");
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}

@@ -1,0 +1,370 @@
+"""Per-State Rejection Sampling on the MI355X: host-side mirror of offsim4rl/evaluators/psrs.py.
+
+  BatchedPSRS   R independent PSRS environments over one device table, stepped by HIP kernels
+  PSRS          the reference's single-environment class (psrs.py:5-57), as BatchedPSRS with R = 1
+  evalMC_psrs   psrs.py:241-271; one kernel launch when given a device-backed env
+  evalmc_rollouts  the batched driver behind the headline metric (thousands of seeds per launch)
+
+Every decision (queue order, accept/reject, state walk, discounted return) is computed on the GPU
+through the C ABI of include/offsim.h; the host only moves arguments and payload.  No CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..table import RolloutState, TransitionTable, seed_streams, seeds_tensor, shuffle_queues
+
+SHUFFLE_PER_ROLLOUT = "per_rollout"  # reset_sampler(seed_r) for every rollout r: the reference's meaning
+SHUFFLE_SHARED = "shared"            # one queue order (shuffle_seed) shared by all rollouts, per-rollout rejection streams
+SHUFFLE_NONE = "table_order"         # queues in buffer order (no shuffle); per-rollout rejection streams
+
+
+def _gamma_pow(gamma, n, device):
+    """gamma**t exactly as the host computes it for the reference (Python float ** int, psrs.py:262)."""
+    g = float(gamma)
+    return torch.tensor([g ** t for t in range(n)], dtype=torch.float64, device=device)
+
+
+def _prob_mode(table, p_dtype):
+    f32 = (p_dtype in (np.float32, torch.float32, np.dtype(np.float32))) and table.p_log.dtype == torch.float32
+    return L.PROB_F32 if f32 else L.PROB_F64
+
+
+class BatchedPSRS:
+    """R PSRS environments sharing one logged-transition table."""
+
+    def __init__(self, table: TransitionTable, R: int, reject_mode=L.REJECT_DEFAULT):
+        self.table, self.R = table, int(R)
+        self.reject_mode = reject_mode
+        self.state = RolloutState(table, R)
+        dev = table.device
+        self._row = torch.empty(R, dtype=torch.int32, device=dev)
+        self._status = torch.empty(R, dtype=torch.int32, device=dev)
+        self._popped = torch.empty(R, dtype=torch.int32, device=dev)
+        self._perm_buf = None
+        self._init_perm_buf = None
+
+    # -- PSRS.reset_sampler (psrs.py:19-30) for all rollouts --
+    def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None):
+        t, dev = self.table, self.table.device
+        sd = seeds_tensor(seeds, dev)
+        assert sd.numel() == self.R, "one seed per rollout"
+        seed_streams(sd, self.state.rng)
+        self.state.rewind()
+        if shuffle == SHUFFLE_PER_ROLLOUT:
+            if self._perm_buf is None or self._perm_buf.shape[0] != self.R:
+                self._perm_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
+                self._init_perm_buf = torch.empty((self.R, max(t.N0, 1)), dtype=torch.int32, device=dev)
+            shuffle_queues(t, sd, self._perm_buf, self._init_perm_buf)
+            self.state.set_orders(self._perm_buf, t.N, self._init_perm_buf, t.N0)
+        elif shuffle == SHUFFLE_SHARED:
+            assert shuffle_seed is not None
+            perm, init_perm = shuffle_queues(t, seeds_tensor([shuffle_seed], dev))
+            self._perm_buf, self._init_perm_buf = perm, init_perm
+            self.state.set_orders(perm, 0, init_perm, 0)
+        elif shuffle == SHUFFLE_NONE:
+            self.state.set_orders(None, 0, None, 0)
+        else:
+            raise ValueError(shuffle)
+
+    def set_rejection_seeds(self, seeds):
+        """Replace only the rejection streams (env.rejection_sampling_rng = default_rng(seed), psrs.py:20)."""
+        seed_streams(seeds_tensor(seeds, self.table.device), self.state.rng)
+
+    # -- PSRS.reset (psrs.py:32-37) --
+    def reset(self, mask=None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        L.check(L.load().offsim_env_reset(C.byref(self.table.c), C.byref(self.state.c), L.ptr(m), L.ptr(self._row), L.stream_ptr()))
+        return self._row
+
+    # -- PSRS.step (psrs.py:39-51) --
+    def step(self, p_new, advance=True, reject_mode=None):
+        """p_new: [R,nA] tensor/array.  Returns device tensors (row, status, popped)."""
+        t = self.table
+        if not isinstance(p_new, torch.Tensor):
+            p_new = torch.from_numpy(np.ascontiguousarray(p_new))
+        mode = _prob_mode(t, p_new.dtype)
+        p = p_new.to(device=t.device, dtype=torch.float32 if mode == L.PROB_F32 else torch.float64).reshape(self.R, t.nA).contiguous()
+        rm = self.reject_mode if reject_mode is None else reject_mode
+        L.check(L.load().offsim_step_batch(C.byref(t.c), C.byref(self.state.c), L.ptr(p), mode, rm, 1 if advance else 0,
+                                           L.ptr(self._row), L.ptr(self._status), L.ptr(self._popped), L.stream_ptr()))
+        return self._row, self._status, self._popped
+
+    def set_state(self, slots, mask=None):
+        s = slots.to(device=self.table.device, dtype=torch.int32).contiguous()
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        L.check(L.load().offsim_env_set_state(C.byref(self.state.c), L.ptr(s), L.ptr(m), L.stream_ptr()))
+
+    # -- evalMC_psrs (psrs.py:241-271) for all rollouts in one launch --
+    def eval_mc(self, pi_slots, gamma, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096, out=None):
+        """pi_slots: [n_slots,nA] policy per state slot (TransitionTable.policy_slots).  Returns a dict of device
+        tensors: sum_g, n_ep, steps, cand, n_len, status (+ ep_g, ep_len, trace_row, trace_pop when asked)."""
+        t, dev, R = self.table, self.table.device, self.R
+        if not isinstance(pi_slots, torch.Tensor):
+            pi_slots = torch.from_numpy(np.ascontiguousarray(pi_slots))
+        mode = _prob_mode(t, pi_slots.dtype)
+        pi_d = pi_slots.to(device=dev, dtype=torch.float32 if mode == L.PROB_F32 else torch.float64).reshape(t.n_slots, t.nA).contiguous()
+        if n_episodes is None:
+            n_episodes = 1 << 62
+        o = out or {}
+        for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64), ("steps", torch.int64), ("cand", torch.int64),
+                      ("n_len", torch.int64), ("status", torch.int32)):
+            if k not in o:
+                o[k] = torch.empty(R, dtype=dt, device=dev)
+        if ep_cap:
+            o["ep_g"] = torch.zeros((R, ep_cap), dtype=torch.float64, device=dev)
+            o["ep_len"] = torch.zeros((R, ep_cap + 1), dtype=torch.int32, device=dev)
+        if trace_cap:
+            o["trace_row"] = torch.full((R, trace_cap), -1, dtype=torch.int32, device=dev)
+            o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
+        gp = _gamma_pow(gamma, n_gamma_pow, dev)
+        oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
+                         n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
+                         ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
+                         trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
+        L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
+                                        L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
+        o["_keepalive"] = (pi_d, gp)
+        return o
+
+
+def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, tile=None,
+                    reject_mode=L.REJECT_DEFAULT, n_episodes=None):
+    """evalMC_psrs for many sampler seeds.  Rollouts are processed in tiles of `tile` seeds so that the per-rollout
+    queue permutations (4*N bytes each) fit the HBM budget.  Returns host arrays: sum_g, n_ep, steps, cand, status
+    and value = sum_g / n_ep (the per-seed value estimate, Gs.mean())."""
+    seeds = np.asarray(seeds, dtype=np.uint64)
+    R = len(seeds)
+    if tile is None:
+        budget = 48 << 30  # bytes of permutation indices kept resident at once
+        tile = R if shuffle != SHUFFLE_PER_ROLLOUT else int(max(1, min(R, budget // max(4 * table.N, 1))))
+    pi_slots = table.policy_slots(pi)
+    outs = {k: [] for k in ("sum_g", "n_ep", "steps", "cand", "status")}
+    env = None
+    for b in range(0, R, tile):
+        sd = seeds[b:b + tile]
+        if env is None or env.R != len(sd):
+            env = BatchedPSRS(table, len(sd), reject_mode)
+        env.reset_sampler(sd, shuffle, shuffle_seed)
+        o = env.eval_mc(pi_slots, gamma, n_episodes)
+        for k in outs:
+            outs[k].append(o[k].cpu().numpy())
+    res = {k: np.concatenate(v) for k, v in outs.items()}
+    with np.errstate(invalid="ignore", divide="ignore"):
+        res["value"] = res["sum_g"] / res["n_ep"]
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's single-environment class
+# ---------------------------------------------------------------------------------------------------
+class PSRS:
+    """Rejection sampler that acts as an environment (psrs.py:5-57), device-backed.
+
+    PSRS(buffer, nS=25, nA=5, reject_func=None): `buffer` is the reference's iterable of legacy tuples
+    (s, a, r, s', done, p, info) with info['z'], info['z_next'|'next_z'], info['t'].  PSRS.from_arrays
+    builds the same object from columns without the per-row Python loop.
+    """
+
+    def __init__(self, buffer, nS=25, nA=5, reject_func=None):
+        rows = list(buffer)
+        self.raw_buffer = rows
+        n = len(rows)
+        z = np.fromiter((r[6]["z"] for r in rows), np.int64, n)
+        zn = np.fromiter((r[6]["z_next"] if "z_next" in r[6] else r[6]["next_z"] for r in rows), np.int64, n)
+        t0 = np.fromiter((r[6]["t"] == 0 for r in rows), bool, n)
+        a = np.fromiter((int(r[1]) for r in rows), np.int64, n)
+        rew = np.array([r[2] for r in rows]) if n else np.zeros(0)
+        done = np.fromiter((bool(r[4]) for r in rows), bool, n)
+        p_log = np.stack([np.asarray(r[5]) for r in rows]) if n else np.zeros((0, nA))
+        self._setup(z, a, rew, zn, done, p_log, t0, nS, nA, reject_func,
+                    obs=[r[0] for r in rows], next_obs=[r[3] for r in rows], infos=[r[6] for r in rows], p_objs=[r[5] for r in rows])
+
+    @classmethod
+    def from_arrays(cls, z, a, r, z_next, done, p_log, t0=None, nS=None, nA=None, reject_func=None, obs=None, next_obs=None,
+                    reject_mode=None):
+        self = cls.__new__(cls)
+        self.raw_buffer = None
+        p_log = np.asarray(p_log)
+        self._setup(np.asarray(z, np.int64), np.asarray(a, np.int64), np.asarray(r), np.asarray(z_next, np.int64),
+                    np.asarray(done, bool), p_log, None if t0 is None else np.asarray(t0, bool),
+                    nS if nS is not None else (int(max(np.max(z), np.max(z_next))) + 1 if len(z) else 1),
+                    nA if nA is not None else p_log.shape[1], reject_func, obs=obs, next_obs=next_obs, reject_mode=reject_mode)
+        return self
+
+    def _setup(self, z, a, r, zn, done, p_log, t0, nS, nA, reject_func, obs=None, next_obs=None, infos=None, p_objs=None,
+               reject_mode=None):
+        self.nS, self.nA = nS, nA
+        self._z, self._a, self._r, self._zn, self._done, self._p_log = z, a, r, zn, done, p_log
+        self._t0 = np.ones(len(z), bool) if t0 is None else t0
+        self._obs = z if obs is None else obs          # observation == latent state unless given
+        self._next_obs = zn if next_obs is None else next_obs
+        self._obs_is_state = obs is None or (len(z) > 0 and _all_equal(obs, z) and _all_equal(next_obs, zn))
+        self._infos, self._p_objs = infos, p_objs
+        self._reject_func = reject_func
+        self.table = TransitionTable(z, a, r, zn, done, p_log, t0)
+        self._env = BatchedPSRS(self.table, 1, L.REJECT_DEFAULT if reject_mode is None else reject_mode)
+        self.s = None
+        self.z = None
+        self.reset_sampler()   # psrs.py:13 (unseeded on construction)
+        self.reset()           # psrs.py:14
+
+    # -- psrs.py:19-30 --
+    def reset_sampler(self, seed=None):
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")  # default_rng(None): fresh OS entropy
+        self._sampler_seed = int(seed)
+        self._env.reset_sampler([seed], SHUFFLE_PER_ROLLOUT)
+
+    # -- psrs.py:32-37 (the seed argument is ignored there too) --
+    def reset(self, seed=None):
+        row = int(self._env.reset().cpu()[0])
+        if row < 0:
+            self.s = None
+            return None
+        self.z = int(self._z[row])
+        self.s = self._obs[row]
+        return self.s
+
+    # -- psrs.py:39-51 --
+    def step(self, p_new):
+        if isinstance(p_new, torch.Tensor):
+            p_new = p_new.detach().cpu().numpy()
+        p_new = np.asarray(p_new)
+        z = self.z
+        if self._reject_func is None:
+            row, status, popped = self._env.step(p_new.reshape(1, -1))
+            row, status = int(row.cpu()[0]), int(status.cpu()[0])
+        else:  # Python-side _reject hook: pop candidates one at a time and ask the callable (psrs.py:48)
+            while True:
+                row, status, _ = self._env.step(p_new.reshape(1, -1), advance=False, reject_mode=L.REJECT_NEVER)
+                row, status = int(row.cpu()[0]), int(status.cpu()[0])
+                if status != L.ST_OK:
+                    break
+                if not self._reject_func(p_new, self._p_of(row), self._a_of(row)):
+                    self._env.set_state(torch.tensor([self.table.slot_of(self._zn[row])]))
+                    break
+        if status == L.ST_KEYERROR:
+            raise KeyError(z)
+        if status in (L.ST_EXHAUSTED, L.ST_INACTIVE):
+            return None, None, None, None
+        self.s = self._next_obs[row]
+        self.z = int(self._zn[row])
+        return self.s, self._r[row], bool(self._done[row]), {"z": z, "a": self._a_of(row), "p": self._p_of(row)}
+
+    def _p_of(self, row):
+        return self._p_objs[row] if self._p_objs is not None else self._p_log[row]
+
+    def _a_of(self, row):
+        return self.raw_buffer[row][1] if self.raw_buffer is not None else self._a[row]
+
+    def _default_reject(self, p_new, p_log, a) -> bool:
+        """psrs.py:53-57.  Only reachable through user hooks that call it explicitly; the draw comes from the
+        device stream so that the sequence stays the reference's."""
+        u = self._draw_uniform()
+        a = int(a)
+        M = (p_new / p_log).max()
+        return u > p_new[a] / p_log[a] / M
+
+    # -- public attributes of the reference object, materialised on demand --
+    @property
+    def rejection_sampling_rng(self):
+        st = self._env.state.rng.cpu().numpy().view(np.uint64)[0]
+        g = np.random.Generator(np.random.PCG64())
+        g.bit_generator.state = {"bit_generator": "PCG64", "state": {"state": (int(st[0]) << 64) | int(st[1]),
+                                 "inc": (int(st[2]) << 64) | int(st[3])}, "has_uint32": 0, "uinteger": 0}
+        return g
+
+    @rejection_sampling_rng.setter
+    def rejection_sampling_rng(self, gen):
+        s = gen.bit_generator.state
+        if s["bit_generator"] != "PCG64":
+            raise ValueError("only PCG64 generators (np.random.default_rng) can drive the device stream")
+        st, inc = s["state"]["state"], s["state"]["inc"]
+        m = (1 << 64) - 1
+        w = np.array([st >> 64, st & m, inc >> 64, inc & m], dtype=np.uint64).view(np.int64)
+        self._env.state.rng.copy_(torch.from_numpy(w.copy()).reshape(1, 4))
+
+    def _draw_uniform(self):
+        g = self.rejection_sampling_rng
+        u = g.random()
+        self.rejection_sampling_rng = g
+        return u
+
+    def _orders(self):
+        t, st = self.table, self._env.state
+        seg = t.seg_off.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        order = t.order.cpu().numpy()
+        perm = st.perm.cpu().numpy().reshape(-1)[: t.N].astype(np.int64) if st.perm is not None else np.arange(t.N)
+        cur = st.cursor.cpu().numpy()[0]
+        return seg, order, perm, cur
+
+    @property
+    def queues(self):
+        """{z: remaining rows of the queue, head first} as caller-buffer row indices (psrs.py:26-30)."""
+        seg, order, perm, cur = self._orders()
+        out = {}
+        for s in range(self.table.n_slots):
+            if seg[s + 1] > seg[s]:
+                out[s + self.table.z_base] = [int(order[g]) for g in perm[seg[s] + cur[s]: seg[s + 1]]]
+        return out
+
+    @property
+    def init_queue(self):
+        st, t = self._env.state, self.table
+        ip = st.init_perm.cpu().numpy().reshape(-1)[: t.N0] if st.init_perm is not None else np.arange(t.N0)
+        rows = t.init_orig.cpu().numpy()[ip]
+        ic = int(st.init_cursor.cpu()[0])
+        return [(int(self._z[r]), self._obs[r]) for r in rows[ic:]]
+
+
+def _all_equal(xs, arr):
+    try:
+        return bool(np.array_equal(np.asarray(xs), arr))
+    except Exception:
+        return False
+
+
+# ---------------------------------------------------------------------------------------------------
+def evalMC_psrs(env, n_episodes, pi, gamma):
+    """psrs.py:241-271.  For a device-backed PSRS whose observations are its latent states and whose reject rule is
+    built in, the whole loop runs in one kernel launch; otherwise the reference's host loop drives env.step."""
+    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and isinstance(pi, np.ndarray) and pi.ndim == 2:
+        t = env.table
+        if pi.shape[0] <= t.z_base + t.n_slots - 1:
+            raise IndexError("pi has no row for some latent state")
+        n_ep = int(min(n_episodes, t.N0 + 1))
+        o = env._env.eval_mc(t.policy_slots(pi), gamma, n_ep, ep_cap=max(n_ep, 1))
+        status = int(o["status"].cpu()[0])
+        if status == L.ST_KEYERROR:
+            raise KeyError(int(env._env.state.cur_slot.cpu()[0]) + t.z_base)
+        ne, nl = int(o["n_ep"].cpu()[0]), int(o["n_len"].cpu()[0])
+        cs = int(env._env.state.cur_slot.cpu()[0])
+        env.z = cs + t.z_base if cs >= 0 else env.z
+        if cs < 0:
+            env.s = None
+        return o["ep_g"].cpu().numpy()[0, :ne].copy(), o["ep_len"].cpu().numpy()[0, :nl].astype(np.int64)
+    Gs, lengths = [], []
+    episode, terminate = 0, False
+    while episode < n_episodes and not terminate:
+        G, t = 0, 0
+        S = env.reset(seed=episode)
+        if S is None:
+            break
+        done = False
+        while not done:
+            S_, R, done, info = env.step(pi[S])
+            if S_ is None:
+                terminate = True
+                break
+            S = S_
+            G = G + (gamma ** t) * R
+            t = t + 1
+        lengths.append(t)
+        if done:
+            Gs.append(G)
+            episode += 1
+    return np.array(Gs), np.array(lengths)
