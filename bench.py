@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: simulated steps/sec (node), 10 M logged transitions x 4096 rollouts.
+
+One "step" = one full pass of the hot path over the batch of rollouts on every rank:
+  PSRS.reset_sampler(seed_r) for all R seeds   (offsim_seed_streams + offsim_shuffle_queues)
+  evalMC_psrs until the buffer is exhausted     (offsim_eval_mc)
+with the logged-transition table already resident in HBM.  value = accepted steps of all rollouts on all
+ranks / wall time (max over ranks).  Multi-GPU = weak scaling: every rank owns its own 10 M-transition shard
+of the log (shards are episode-disjoint), runs all R seeds on it, and the per-seed (sum G, n episodes) pairs
+are combined with one RCCL all-reduce.
+
+Prints ONE JSON line on rank 0; see README/DESIGN.md for the fields `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--transitions", type=int, default=10_000_000, help="logged transitions per GPU")
+    ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts) per GPU")
+    ap.add_argument("--n-states", type=int, default=162)
+    ap.add_argument("--n-actions", type=int, default=2)
+    ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
+    ap.add_argument("--tile", type=int, default=1024, help="rollouts whose queue permutations are resident at once")
+    ap.add_argument("--gamma", type=float, default=0.99)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-transitions", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(e, pi, gamma, n_sample, budget_s):
+    """The oracle (C port of the reference loop, one thread) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    sl = slice(0, n_sample)
+    t0 = e["steps"][sl] == 0
+    ora = O.OraclePSRS(e["z"][sl], e["actions"][sl], e["rewards"][sl], e["z_next"][sl], e["terminals"][sl],
+                       e["action_distributions"][sl], t0)
+    steps, n_roll = 0, 0
+    t_start = time.perf_counter()
+    while True:
+        ora.reset_sampler(n_roll)
+        res = ora.evalmc(10 ** 9, pi, gamma)
+        steps += res["steps"]
+        n_roll += 1
+        el = time.perf_counter() - t_start
+        if el > budget_s or n_roll >= 4096:
+            break
+    return {"value": steps / el, "unit": "simulated steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_roll} rollouts (reset_sampler + evalMC to exhaustion) over the first {n_sample} transitions of the "
+                      f"same synthetic log, {el:.1f} s of oracle/psrs_oracle.c on one host core"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from rl_offline_simulation_amd import _lib, synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    from rl_offline_simulation_amd.distributed import allreduce_estimates
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the PSRS engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.load()
+
+    N, R = a.transitions, a.rollouts
+    # this rank's shard of the log: shard g is generated from seed 20221107 + g (episode-disjoint by construction)
+    e = synth.synth_iid(N, a.n_states, a.n_actions, seed=20221107 + rank)
+    pi = synth.dirichlet_policy(a.n_states, a.n_actions)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=dev)
+    pi_slots = table.policy_slots(pi)
+    seeds = np.arange(R, dtype=np.uint64)
+    tile = min(a.tile, R)
+    envs = {}
+
+    def env_for(n):
+        if n not in envs:
+            envs[n] = BatchedPSRS(table, n)
+        return envs[n]
+
+    acc = {k: torch.zeros(R, dtype=dt, device=dev) for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64),
+                                                                   ("steps", torch.int64), ("cand", torch.int64))}
+    ev = []  # (kind, start, stop) HIP events on the launch stream
+
+    def one_pass(record):
+        for b in range(0, R, tile):
+            sd = seeds[b:b + tile]
+            env = env_for(len(sd))
+            if record:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            env.reset_sampler(sd, a.shuffle, shuffle_seed=1234)
+            if record:
+                e1.record()
+            o = env.eval_mc(pi_slots, a.gamma)
+            if record:
+                e2.record()
+                ev.append(("reset_sampler", e0, e1))
+                ev.append(("scan", e1, e2))
+            for k in acc:
+                acc[k][b:b + len(sd)] = o[k]
+        est = torch.stack([acc["sum_g"], acc["n_ep"].to(torch.float64)], dim=1)
+        if world > 1:
+            allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096)
+        return est
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_pass(False)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(a.steps):
+        est = one_pass(True)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    steps_t = torch.stack([acc["steps"].sum(), acc["cand"].sum()]).to(torch.float64)
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)
+    elapsed = float(el_t[0])
+    steps_pass, cand_pass = float(steps_t[0]), float(steps_t[1])  # all ranks, one pass
+
+    if rank == 0:
+        t_scan = sum(s.elapsed_time(t) for k, s, t in ev if k == "scan") * 1e-3
+        t_reset = sum(s.elapsed_time(t) for k, s, t in ev if k == "reset_sampler") * 1e-3
+        n_scan = sum(1 for k, _, _ in ev if k == "scan")
+        my_steps, my_cand = float(acc["steps"].sum()), float(acc["cand"].sum())
+        b_c = table.bytes_per_candidate + (4 if a.shuffle != "table_order" else 0)  # + permutation index
+        b_s = table.bytes_per_step
+        alg_bytes_pass = my_cand * b_c + my_steps * b_s
+        achieved = alg_bytes_pass * a.steps / t_scan / 1e9
+        value = steps_pass * a.steps / elapsed
+        vest = (est[:, 0] / est[:, 1]).cpu().numpy()
+        out = {
+            "metric": "simulated steps/sec (node), 10M logged transitions x 4096 rollouts",
+            "value": value, "unit": "simulated steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
+                                   f"evalMC_psrs to exhaustion, gamma={a.gamma}", "transitions_per_gpu": N, "rollouts": R,
+                       "shuffle": a.shuffle, "rollout_tile": tile, "p_log": "f32", "sharding": f"log sharded by episode over {world} GPU(s), "
+                       "all seeds on every shard, RCCL all-reduce of per-seed (sum G, n episodes)"},
+            "candidates_per_s": cand_pass * a.steps / elapsed, "acceptance": steps_pass / max(cand_pass, 1.0),
+            "buffer_consumed_frac": cand_pass / (world * R * N),
+            "value_estimate_mean": float(np.nanmean(vest)),
+            "scan_only_steps_per_s": my_steps * a.steps / t_scan, "reset_sampler_s_per_pass": t_reset / a.steps,
+            "scan_s_per_pass": t_scan / a.steps,
+            "roofline": {"bound": "hbm", "kernel": "k_eval_mc", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_pass / max(n_scan / a.steps, 1),
+                         "bytes_per_candidate": b_c, "bytes_per_step": b_s, "launches": n_scan,
+                         "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(e, pi, a.gamma, min(a.cpu_sample_transitions, N), a.cpu_sample_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
