@@ -166,6 +166,18 @@ int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, i
                    double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
                    const offsim_evalmc_out *out, void *stream);
 
+/* Fast path of evalMC_psrs for a fixed tabular policy (the headline scan).
+ * offsim_compile_policy folds psrs.py:53-57 for policy pi [n_slots,nA] f64 into one 64-bit key per grouped row:
+ *   key = T << 11 | done << 10 | z_next_slot,  T = floor(2^53 * pi[z][a]/p_log[a]/max_a'(pi[z][a']/p_log[a'])),
+ * so that  reject <=> u > threshold <=> (53-bit draw) > T, exactly (NaN or >= 1 thresholds give T = 2^53-1).
+ * Needs n_slots <= 1024.  keys_out: [N] uint64, caller-owned.
+ * offsim_eval_mc_keys runs the same loop as offsim_eval_mc (OFFSIM_PROB_F64, OFFSIM_REJECT_DEFAULT) from those keys,
+ * with per-state candidate windows in LDS; n_slots <= 256, otherwise OFFSIM_EUNSUPPORTED (use offsim_eval_mc). */
+int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream);
+int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
+                        const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
+                        void *stream);
+
 /* ---- encoders (a10, a11) --------------------------------------------------------------------- */
 
 /* CartpoleBoxEncoder.encode (offsim4rl/encoders/heuristic.py:19-71): obs [N,4] f32 -> z [N] i32 in -1..161 */

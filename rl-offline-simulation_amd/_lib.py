@@ -53,6 +53,9 @@ SIGNATURES = {
     "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), _vp]),
+    "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
+    "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
+                                      C.POINTER(EvalMCOut), _vp]),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
     "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
 }

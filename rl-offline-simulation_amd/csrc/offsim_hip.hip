@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) k_step_batch(offsim_table t, offsim_rollo
                                                     int32_t *__restrict__ out_row, int32_t *__restrict__ out_status,
                                                     uint32_t *__restrict__ out_popped) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);  // uniform -> SGPR
     const int r = blockIdx.x * (blockDim.x / WAVE) + wave;
     if (r >= ro.R) return;
     int slot = ro.cur_slot[r];
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
                                                  int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int waves = blockDim.x / WAVE;
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);  // uniform -> SGPR
     const int n_slots = t.n_slots, nA = t.nA;
     // LDS carve: [jump tables][pi][seg_off][cursors per wave]
     Jump *tables = (Jump *)lds_raw;
@@ -697,6 +697,63 @@ extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const 
     else if (t->plog_dtype == OFFSIM_F64) LAUNCH_MC(double, double);
     else LAUNCH_MC(__half, double);
 #undef LAUNCH_MC
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast evalMC scan: compiled-policy keys + LDS candidate windows (scan_win.hpp)
+// ------------------------------------------------------------------------------------------------
+#include "scan_win.hpp"
+
+extern "C" int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!pi || (t->N > 0 && !keys_out)) return fail(OFFSIM_EINVAL, "compile_policy: bad argument%s");
+    if (t->n_slots > 1024) return fail(OFFSIM_EUNSUPPORTED, "compile_policy: more than 1024 states do not fit the 10-bit next-state field%s");
+    if (t->N == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((t->N + 255) / 256)), block(256);
+    size_t lds = sizeof(uint32_t) * (t->n_slots + 1);
+    if (t->plog_dtype == OFFSIM_F32) hipLaunchKernelGGL(k_compile_policy<float>, grid, block, lds, st, *t, pi, keys_out);
+    else if (t->plog_dtype == OFFSIM_F64) hipLaunchKernelGGL(k_compile_policy<double>, grid, block, lds, st, *t, pi, keys_out);
+    else hipLaunchKernelGGL(k_compile_policy<__half>, grid, block, lds, st, *t, pi, keys_out);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
+                                   const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
+                                   const offsim_evalmc_out *out, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !out || (t->N > 0 && !keys)) return fail(OFFSIM_EINVAL, "eval_mc_keys: bad argument%s");
+    if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
+        return fail(OFFSIM_EINVAL, "eval_mc_keys: required output is NULL%s");
+    if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: candidate windows support at most 256 states%s");
+    if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_keys: gamma_pow is NULL%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int waves = 4;
+    dim3 grid((ro->R + waves - 1) / waves), block(waves * 64);
+    const bool trace = out->trace_row || out->trace_pop;
+    const int rounds = (t->n_slots + 63) / 64;
+#define LAUNCH_WIN(W, ROUNDS)                                                                                         \
+    do {                                                                                                              \
+        size_t lds = (size_t)waves * ((size_t)t->n_slots * (W) * 8 + OFFSIM_RING * 4);                                \
+        if (trace)                                                                                                    \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, false>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+    } while (0)
+    // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
+    if (rounds == 1) LAUNCH_WIN(16, 1);
+    else if (rounds == 2) LAUNCH_WIN(8, 2);
+    else if (rounds == 3) LAUNCH_WIN(6, 3);
+    else LAUNCH_WIN(4, 4);
+#undef LAUNCH_WIN
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }

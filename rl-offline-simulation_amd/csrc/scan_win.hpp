@@ -1,0 +1,404 @@
+// scan_win.hpp -- the fast evalMC scan: compiled-policy keys + per-state candidate windows in LDS.
+//
+// Why: a PSRS rollout is one long dependent chain (state -> head of that state's queue -> accept ->
+// next state).  Reading the queue head from HBM on every step costs a DRAM round trip (two with a
+// per-rollout permutation) per simulated step.  Here the next few candidates of EVERY state's queue
+// are kept in an LDS window per rollout, so the chain runs at LDS/ALU latency, and the HBM traffic
+// (permutation indices + 8-byte candidate keys) is issued in lane-parallel refill phases every 64
+// accepted steps, two phases ahead of use (software pipeline A: indices, B: keys, C: land in LDS).
+//
+// Compiled policy (offsim_compile_policy): for a fixed tabular policy pi the rejection test of
+// psrs.py:53-57 depends only on the row, so it is folded into one 64-bit key per grouped row:
+//     key = [T>>32 : 21 | done : 1 | z_next_slot : 10 | T & 0xffffffff : 32],  T = floor(thr * 2^53),
+//     thr = pi[z][a]/p_log[a]/M
+// and  reject  <=>  u > thr  <=>  k53 > T  with u = k53 * 2^-53 (exact; NaN/>=1 thr -> T = 2^53-1).
+// Windows hold the high dword (the "digest": top 21 bits of T | done | z_next) next to the row id; a
+// draw whose top 21 bits tie with the digest (p = 2^-21) is resolved exactly on the slow path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "offsim.h"
+#include "pcg64_dev.hpp"
+
+namespace offsim {
+
+#define OFFSIM_RING 128  // draws kept ahead per rollout (power of two >= 2*64)
+#define OFFSIM_PH 64     // accepted steps per refill phase (lane i stages step i's reward)
+
+__device__ __forceinline__ uint64_t pack_key(double thr, int done, int zn) {
+    uint64_t T;
+    if (thr != thr || thr >= 1.0) T = (1ull << 53) - 1;  // NaN compares false -> never rejected; u < 1 <= thr
+    else if (thr < 0.0) T = 0;                          // cannot happen for probabilities
+    else T = (uint64_t)floor(thr * 9007199254740992.0);  // exact power-of-two scaling
+    return ((T >> 32) << 43) | ((uint64_t)(done ? 1 : 0) << 42) | ((uint64_t)(zn & 1023) << 32) | (T & 0xffffffffull);
+}
+__device__ __forceinline__ uint64_t key_T(uint64_t key) { return ((key >> 43) << 32) | (key & 0xffffffffull); }
+
+// rare paths kept out of line so that they do not inflate the register budget of the chain loop
+__device__ __forceinline__ uint64_t exact_draw53(U128 base, U128 inc, uint64_t n_steps) {
+    return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
+}
+__device__ __forceinline__ double pow_fallback(double gamma, double t) { return pow(gamma, t); }
+
+template <typename PL>
+__global__ void k_compile_policy(offsim_table t, const double *__restrict__ pi, uint64_t *__restrict__ keys) {
+    extern __shared__ uint32_t seg_lds[];
+    for (int i = threadIdx.x; i <= t.n_slots; i += blockDim.x) seg_lds[i] = t.seg_off[i];
+    __syncthreads();
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= t.N) return;
+    int lo = 0, hi = t.n_slots;  // slot with seg_off[slot] <= g < seg_off[slot+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (seg_lds[mid] <= (uint32_t)g) lo = mid;
+        else hi = mid;
+    }
+    const double *pnew = pi + (size_t)lo * t.nA;
+    const PL *plog = (const PL *)t.p_log;
+    const int nA = t.nA, a = t.a[g];
+    double M = -__builtin_inf();
+    bool nan = false;
+    for (int k = 0; k < nA; k++) {
+        double q = pnew[k] / plog_f64<PL>(plog, g * nA + k);
+        nan |= (q != q);
+        M = q > M ? q : M;
+    }
+    if (nan) M = __builtin_nan("");
+    double thr = pnew[a] / plog_f64<PL>(plog, g * nA + a) / M;
+    keys[g] = pack_key(thr, t.done[g], t.z_next[g]);
+}
+
+template <int ROUNDS>
+__device__ __forceinline__ uint32_t rd_lane(const uint32_t (&v)[ROUNDS], int q, int l) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; i++) {
+        uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v[i], l);
+        r = (q == i) ? x : r;
+    }
+    return r;
+}
+template <int ROUNDS>
+__device__ __forceinline__ void wr_lane(uint32_t (&v)[ROUNDS], int q, int l, uint32_t val) {
+    const int lane = threadIdx.x & 63;  // (this clang has no writelane builtin: predicated move instead)
+#pragma unroll
+    for (int i = 0; i < ROUNDS; i++) v[i] = (q == i && lane == l) ? val : v[i];
+}
+
+// W = window entries per state, ROUNDS = ceil(n_slots / 64), D = entries requested per state per phase.
+template <int W, int ROUNDS, bool TRACE>
+__global__ void __launch_bounds__(256, 4)
+    k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
+                  const double *__restrict__ gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out) {
+    constexpr int D = (W / 2) > 8 ? 8 : (W / 2);
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int waves = blockDim.x / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;  // wave id is uniform: keep it scalar
+    const int n_slots = t.n_slots;
+    const size_t win_bytes = (size_t)n_slots * W * 8;
+    uint64_t *win = (uint64_t *)(lds_raw + (size_t)wave * (win_bytes + OFFSIM_RING * 4));
+    uint32_t *ring = (uint32_t *)((unsigned char *)win + win_bytes);
+    const int r = blockIdx.x * waves + wave;
+    if (r >= ro.R) return;
+
+    const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
+    const uint32_t *init_row = ro.init_perm ? ro.init_perm + (int64_t)r * ro.init_stride : nullptr;
+    uint32_t *cur_glb = ro.cursor + (int64_t)r * n_slots;
+
+    // ---- per-state registers: lane l of round q owns state q*64+l ----
+    uint32_t cur[ROUNDS], landed[ROUNDS], fill[ROUNDS], beg[ROUNDS], len[ROUNDS];
+    uint32_t idxA[ROUNDS][D], posA[ROUNDS], cntA[ROUNDS];
+    uint32_t digB[ROUNDS][D];
+    uint32_t gB[ROUNDS][D], posB[ROUNDS], cntB[ROUNDS];
+    const uint32_t *keys32 = (const uint32_t *)keys;
+#pragma unroll
+    for (int q = 0; q < ROUNDS; q++) {
+        int s = q * 64 + lane;
+        bool ok = s < n_slots;
+        uint32_t b = ok ? t.seg_off[s] : 0u, e = ok ? t.seg_off[s + 1] : 0u;
+        beg[q] = b;
+        len[q] = e - b;
+        cur[q] = ok ? cur_glb[s] : 0u;
+        landed[q] = fill[q] = cur[q];
+        posA[q] = cntA[q] = posB[q] = cntB[q] = 0;
+#pragma unroll
+        for (int e2 = 0; e2 < D; e2++) {
+            idxA[q][e2] = 0;
+            digB[q][e2] = 0;
+            gB[q][e2] = 0;
+        }
+    }
+    auto stageC = [&]() {  // land the keys gathered one phase ago
+#pragma unroll
+        for (int q = 0; q < ROUNDS; q++) {
+            int s = q * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < D; e++) {
+                uint32_t pos = posB[q] + e;
+                if ((uint32_t)e < cntB[q] && pos >= cur[q]) {
+                    win[(size_t)s * W + pos % W] = ((uint64_t)gB[q][e] << 32) | digB[q][e];
+                }
+            }
+            uint32_t end = posB[q] + cntB[q];
+            if (cntB[q] && posB[q] <= landed[q] && end > landed[q]) landed[q] = end;
+            cntB[q] = 0;
+        }
+    };
+    auto stageB = [&]() {  // permutation indices have arrived: gather the digests (high dword of each key)
+#pragma unroll
+        for (int q = 0; q < ROUNDS; q++) {
+#pragma unroll
+            for (int e = 0; e < D; e++) {
+                if ((uint32_t)e < cntA[q]) {
+                    uint32_t g = idxA[q][e];
+                    gB[q][e] = g;
+                    digB[q][e] = keys32[2 * (size_t)g + 1];
+                }
+            }
+            posB[q] = posA[q];
+            cntB[q] = cntA[q];
+            cntA[q] = 0;
+        }
+    };
+    auto stageA = [&]() {  // request the next entries of every state's queue
+#pragma unroll
+        for (int q = 0; q < ROUNDS; q++) {
+            uint32_t have = fill[q] - cur[q];
+            uint32_t room = have < (uint32_t)W ? (uint32_t)W - have : 0u;
+            uint32_t left = len[q] - fill[q];
+            uint32_t want = room < (uint32_t)D ? room : (uint32_t)D;
+            want = want < left ? want : left;
+            posA[q] = fill[q];
+            cntA[q] = want;
+#pragma unroll
+            for (int e = 0; e < D; e++) {
+                if ((uint32_t)e < want) {
+                    uint32_t p = beg[q] + fill[q] + e;
+                    idxA[q][e] = perm_row ? perm_row[p] : p;
+                }
+            }
+            fill[q] += want;
+        }
+    };
+    // synchronous priming: two full A-B-C rounds fill every window
+    stageA();
+    stageB();
+    stageC();
+    stageA();
+    stageB();
+    stageC();
+
+    // ---- rejection stream: ring of the top 21 bits of the next draws ----
+    const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+    const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+    const Jump j64 = pcg_jump(inc, 64);
+    U128 lane_state = pcg_apply(pcg_jump(inc, (uint64_t)lane + 1), base);  // yields draw `lane`
+    uint64_t gen = 0, c = 0;                                                // draws generated / consumed
+    auto gen_block = [&]() {
+        ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43);
+        lane_state = pcg_apply(j64, lane_state);
+        gen += 64;
+    };
+    gen_block();
+    gen_block();
+
+    // ---- initial-state prefetch: lane i holds the slot of init index ib+i ----
+    uint32_t ic = ro.init_cursor[r], ib = ic;
+    int init_reg = -1;
+    auto load_init = [&]() {
+        ib = ic;
+        uint32_t k = ic + lane;
+        int v = -1;
+        if ((int64_t)k < t.N0) v = t.init_slot[init_row ? init_row[k] : k];
+        init_reg = v;
+    };
+    load_init();
+
+    int slot = ro.cur_slot[r];
+    int64_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, cand = 0, len_acc = 0, tt = 0;
+    double sum_g = 0.0, G = 0.0;
+    int status = OFFSIM_ST_OK;
+    // per-phase staging: lane i holds reward and discount of the phase's i-th accepted step
+    double r_val = 0.0, gp_val = 0.0;
+    uint64_t done_mask = 0;
+    int nph = 0;
+    uint32_t pop_acc = 0;
+    const bool r64 = t.r_dtype == OFFSIM_F64;
+
+    auto flush = [&]() {  // in-order discounted-return accumulation (psrs.py:262-269), then the refill pipeline
+        double prod = gp_val * r_val;
+        for (int i = 0; i < nph; i++) {
+            G = G + readlane_f64(prod, i);
+            len_acc++;
+            if ((done_mask >> i) & 1ull) {
+                if (lane == 0) {
+                    if (out.ep_g && ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
+                    if (out.ep_len && n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
+                }
+                sum_g += G;
+                ep_acc++;
+                n_len++;
+                G = 0.0;
+                len_acc = 0;
+            }
+        }
+        nph = 0;
+        done_mask = 0;
+        stageC();
+        stageB();
+        stageA();
+    };
+
+    bool need_reset = true;  // evalMC_psrs starts every episode with env.reset() (psrs.py:249)
+    while (true) {
+        if (need_reset) {
+            if (ep >= max_episodes) break;
+            if ((int64_t)ic >= t.N0) {  // psrs.py:33-35, 250-252
+                status = OFFSIM_ST_NO_INIT;
+                slot = -1;
+                break;
+            }
+            if (ic - ib >= 64) load_init();
+            slot = __builtin_amdgcn_readlane(init_reg, (int)(ic - ib));
+            ic++;
+            tt = 0;
+            need_reset = false;
+        }
+        const int q = slot >> 6, l = slot & 63;
+        const uint32_t len_z = rd_lane<ROUNDS>(len, q, l);
+        if (len_z == 0) {  // KeyError (psrs.py:44)
+            status = OFFSIM_ST_KEYERROR;
+            break;
+        }
+        uint32_t cur_z = rd_lane<ROUNDS>(cur, q, l);
+        const uint32_t land_z = rd_lane<ROUNDS>(landed, q, l);
+        const uint32_t avail = land_z - cur_z;
+        bool accepted = false, slow = (avail == 0);
+        uint32_t acc_dig = 0, acc_g = 0, d = 0;
+        if (!slow) {
+            const uint32_t nv = avail < (uint32_t)W ? avail : (uint32_t)W;
+            const bool valid = (uint32_t)lane < nv;
+            uint64_t e = 0;
+            if (valid) e = win[(size_t)slot * W + (cur_z + lane) % W];
+            const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
+            const uint32_t dig = (uint32_t)e, Tt = dig >> 11;
+            const uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+            const uint64_t m = macc | mamb;
+            if (m == 0) {
+                d = nv;  // every window candidate rejected
+            } else {
+                const int f = __ffsll((unsigned long long)m) - 1;
+                if ((mamb >> f) & 1ull) slow = true;  // top-21-bit tie: needs the exact compare
+                else {
+                    accepted = true;
+                    d = (uint32_t)f + 1;
+                    acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
+                    acc_g = (uint32_t)__builtin_amdgcn_readlane((int)(e >> 32), f);
+                }
+            }
+        }
+        if (slow) {  // window empty or tie: 64 candidates straight from HBM with full keys
+            const uint32_t rem = len_z - cur_z;
+            if (rem == 0) {  // psrs.py:44-45
+                status = OFFSIM_ST_EXHAUSTED;
+                break;
+            }
+            const uint32_t nv = rem < 64u ? rem : 64u;
+            const bool valid = (uint32_t)lane < nv;
+            const uint32_t beg_z = rd_lane<ROUNDS>(beg, q, l);
+            uint32_t p = beg_z + cur_z + (valid ? lane : 0);
+            const uint32_t g = perm_row ? perm_row[p] : p;
+            const uint64_t key = keys[g];
+            const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
+            const uint32_t Tt = (uint32_t)(key >> 43);
+            uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+            int f = -1;
+            while (true) {
+                const uint64_t m = macc | mamb;
+                if (m == 0) break;
+                const int ff = __ffsll((unsigned long long)m) - 1;
+                if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
+                    const uint64_t k53 = exact_draw53(base, inc, c + (uint64_t)ff + 1);
+                    const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
+                    const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
+                    const uint64_t Tf = key_T(((uint64_t)khi << 32) | klo);
+                    if (k53 > Tf) {
+                        mamb &= ~(1ull << ff);
+                        continue;
+                    }
+                }
+                f = ff;
+                break;
+            }
+            if (f < 0) d = nv;
+            else {
+                accepted = true;
+                d = (uint32_t)f + 1;
+                acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
+                acc_g = (uint32_t)__builtin_amdgcn_readlane((int)g, f);
+            }
+            cur_z += d;
+            wr_lane<ROUNDS>(cur, q, l, cur_z);
+            const uint32_t fz = rd_lane<ROUNDS>(fill, q, l);
+            if (land_z < cur_z) wr_lane<ROUNDS>(landed, q, l, cur_z);
+            if (fz < cur_z) wr_lane<ROUNDS>(fill, q, l, cur_z);
+        } else {
+            cur_z += d;
+            wr_lane<ROUNDS>(cur, q, l, cur_z);
+        }
+        c += d;
+        cand += d;
+        pop_acc += d;
+        while (gen < c + 64) gen_block();
+        if (accepted) {
+            if (lane == nph) {
+                r_val = r64 ? ((const double *)t.r)[acc_g] : (double)((const float *)t.r)[acc_g];
+                gp_val = tt < n_gamma_pow ? gamma_pow[tt] : pow_fallback(gamma, (double)tt);
+            }
+            const bool dn = (acc_dig >> 10) & 1u;
+            if (dn) done_mask |= 1ull << nph;
+            if (TRACE && lane == 0) {
+                if (out.trace_row && steps < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + steps] = t.orig_idx[acc_g];
+                if (out.trace_pop && steps < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + steps] = pop_acc;
+            }
+            pop_acc = 0;
+            nph++;
+            steps++;
+            tt++;
+            slot = (int)(acc_dig & 1023u);
+            if (dn) {
+                ep++;
+                need_reset = true;
+            }
+            if (nph == OFFSIM_PH) flush();
+        }
+    }
+    flush();
+    if (status == OFFSIM_ST_EXHAUSTED && !need_reset) n_len++;  // psrs.py:265: the cut-short episode still logs its length
+    if (status == OFFSIM_ST_EXHAUSTED && !need_reset && lane == 0 && out.ep_len && n_len - 1 <= out.ep_cap)
+        out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len - 1] = (int32_t)len_acc;
+    // ---- write the env state back ----
+#pragma unroll
+    for (int q = 0; q < ROUNDS; q++) {
+        int s = q * 64 + lane;
+        if (s < n_slots) cur_glb[s] = cur[q];
+    }
+    if (lane == 0) {
+        ro.init_cursor[r] = ic;
+        ro.cur_slot[r] = slot;
+        if (c) {
+            U128 nb = pcg_apply(pcg_jump(inc, c), base);
+            ro.rng[4 * r + 0] = nb.hi;
+            ro.rng[4 * r + 1] = nb.lo;
+        }
+        out.sum_g[r] = sum_g;
+        out.n_ep[r] = ep_acc;
+        out.steps[r] = steps;
+        out.cand[r] = cand;
+        out.n_len[r] = n_len;
+        out.status[r] = status;
+    }
+}
+
+}  // namespace offsim

@@ -99,9 +99,11 @@ class BatchedPSRS:
         L.check(L.load().offsim_env_set_state(C.byref(self.state.c), L.ptr(s), L.ptr(m), L.stream_ptr()))
 
     # -- evalMC_psrs (psrs.py:241-271) for all rollouts in one launch --
-    def eval_mc(self, pi_slots, gamma, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096, out=None):
+    def eval_mc(self, pi_slots, gamma, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096, out=None, fast=None):
         """pi_slots: [n_slots,nA] policy per state slot (TransitionTable.policy_slots).  Returns a dict of device
-        tensors: sum_g, n_ep, steps, cand, n_len, status (+ ep_g, ep_len, trace_row, trace_pop when asked)."""
+        tensors: sum_g, n_ep, steps, cand, n_len, status (+ ep_g, ep_len, trace_row, trace_pop when asked).
+        fast=None picks the compiled-policy / LDS-window kernel (offsim_eval_mc_keys) whenever it applies
+        (f64 probabilities, default reject rule, <= 256 states); fast=False forces the generic kernel."""
         t, dev, R = self.table, self.table.device, self.R
         if not isinstance(pi_slots, torch.Tensor):
             pi_slots = torch.from_numpy(np.ascontiguousarray(pi_slots))
@@ -125,10 +127,29 @@ class BatchedPSRS:
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
                          trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
-        L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
-                                        L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
-        o["_keepalive"] = (pi_d, gp)
+        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256
+        if fast is None:
+            fast = can_fast
+        if fast and not can_fast:
+            raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule and <= 256 states")
+        if fast:
+            keys = self.compile_policy(pi_d)
+            L.check(L.load().offsim_eval_mc_keys(C.byref(t.c), C.byref(self.state.c), L.ptr(keys), float(gamma), L.ptr(gp),
+                                                 gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
+            o["_keepalive"] = (pi_d, gp, keys)
+        else:
+            L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
+                                            L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
+            o["_keepalive"] = (pi_d, gp)
         return o
+
+    def compile_policy(self, pi_d):
+        """offsim_compile_policy: one 64-bit key per grouped row for the tabular policy pi_d [n_slots,nA] f64 (device)."""
+        t = self.table
+        if getattr(self, "_keys", None) is None:
+            self._keys = torch.empty(max(t.N, 1), dtype=torch.int64, device=t.device)
+        L.check(L.load().offsim_compile_policy(C.byref(t.c), L.ptr(pi_d), L.ptr(self._keys), L.stream_ptr()))
+        return self._keys
 
 
 def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, tile=None,
