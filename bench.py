@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--n-states", type=int, default=162)
     ap.add_argument("--n-actions", type=int, default=2)
     ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
-    ap.add_argument("--tile", type=int, default=1024, help="rollouts whose queue permutations are resident at once")
+    ap.add_argument("--tile", type=int, default=4096, help="rollouts whose queue permutations are resident at once")
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-transitions", type=int, default=1_000_000)

@@ -160,6 +160,8 @@ typedef struct offsim_evalmc_out {
     int32_t *trace_row;
     uint32_t *trace_pop;
     int64_t trace_cap;
+    int64_t *dbg; /* optional [R,4] counters of offsim_eval_mc_keys: window-dry events, digest ties, refill phases,
+                     64-draw blocks generated; NULL to skip */
 } offsim_evalmc_out;
 
 int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, int32_t prob_mode, int32_t reject_mode,

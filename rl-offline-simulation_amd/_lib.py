@@ -35,7 +35,7 @@ class EvalMCOut(C.Structure):
     """struct offsim_evalmc_out"""
     _fields_ = [("sum_g", _vp), ("n_ep", _vp), ("steps", _vp), ("cand", _vp), ("n_len", _vp), ("status", _vp),
                 ("ep_g", _vp), ("ep_len", _vp), ("ep_cap", _i64), ("trace_row", _vp), ("trace_pop", _vp),
-                ("trace_cap", _i64)]
+                ("trace_cap", _i64), ("dbg", _vp)]
 
 
 # name -> (restype, argtypes): exactly the entry points include/offsim.h declares

@@ -12,7 +12,7 @@
 //     key = [T>>32 : 21 | done : 1 | z_next_slot : 10 | T & 0xffffffff : 32],  T = floor(thr * 2^53),
 //     thr = pi[z][a]/p_log[a]/M
 // and  reject  <=>  u > thr  <=>  k53 > T  with u = k53 * 2^-53 (exact; NaN/>=1 thr -> T = 2^53-1).
-// Windows hold the high dword (the "digest": top 21 bits of T | done | z_next) next to the row id; a
+// Windows hold the high dword (the "digest": top 21 bits of T | done | z_next); a
 // draw whose top 21 bits tie with the digest (p = 2^-21) is resolved exactly on the slow path.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -87,17 +87,19 @@ __device__ __forceinline__ void wr_lane(uint32_t (&v)[ROUNDS], int q, int l, uin
 }
 
 // W = window entries per state, ROUNDS = ceil(n_slots / 64), D = entries requested per state per phase.
+// Everything the chain touches per step is wave-uniform (SGPRs) except the per-state registers, which are
+// read with v_readlane; counters are 32-bit (N < 2^31) to keep the scalar register file from spilling.
 template <int W, int ROUNDS, bool TRACE>
 __global__ void __launch_bounds__(256, 4)
     k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
-                  const double *__restrict__ gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out) {
-    constexpr int D = (W / 2) > 8 ? 8 : (W / 2);
+                  const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out) {
+    constexpr int D = W / 2;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int waves = blockDim.x / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;  // wave id is uniform: keep it scalar
     const int n_slots = t.n_slots;
-    const size_t win_bytes = (size_t)n_slots * W * 8;
-    uint64_t *win = (uint64_t *)(lds_raw + (size_t)wave * (win_bytes + OFFSIM_RING * 4));
+    const uint32_t win_bytes = (uint32_t)n_slots * W * 4;
+    uint32_t *win = (uint32_t *)(lds_raw + (size_t)wave * (win_bytes + OFFSIM_RING * 4));
     uint32_t *ring = (uint32_t *)((unsigned char *)win + win_bytes);
     const int r = blockIdx.x * waves + wave;
     if (r >= ro.R) return;
@@ -105,13 +107,15 @@ __global__ void __launch_bounds__(256, 4)
     const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
     const uint32_t *init_row = ro.init_perm ? ro.init_perm + (int64_t)r * ro.init_stride : nullptr;
     uint32_t *cur_glb = ro.cursor + (int64_t)r * n_slots;
+    const uint32_t *keys32 = (const uint32_t *)keys;
+    const uint32_t N0 = (uint32_t)t.N0;
+    const uint32_t n_gamma_pow = (uint32_t)(n_gamma_pow64 > 0x7fffffffll ? 0x7fffffffll : n_gamma_pow64);
+    const uint32_t max_episodes = (uint32_t)(max_episodes64 > 0xffffffffll ? 0xffffffffll : max_episodes64);
 
     // ---- per-state registers: lane l of round q owns state q*64+l ----
     uint32_t cur[ROUNDS], landed[ROUNDS], fill[ROUNDS], beg[ROUNDS], len[ROUNDS];
     uint32_t idxA[ROUNDS][D], posA[ROUNDS], cntA[ROUNDS];
-    uint32_t digB[ROUNDS][D];
-    uint32_t gB[ROUNDS][D], posB[ROUNDS], cntB[ROUNDS];
-    const uint32_t *keys32 = (const uint32_t *)keys;
+    uint32_t digB[ROUNDS][D], posB[ROUNDS], cntB[ROUNDS];
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
         int s = q * 64 + lane;
@@ -123,22 +127,16 @@ __global__ void __launch_bounds__(256, 4)
         landed[q] = fill[q] = cur[q];
         posA[q] = cntA[q] = posB[q] = cntB[q] = 0;
 #pragma unroll
-        for (int e2 = 0; e2 < D; e2++) {
-            idxA[q][e2] = 0;
-            digB[q][e2] = 0;
-            gB[q][e2] = 0;
-        }
+        for (int e2 = 0; e2 < D; e2++) idxA[q][e2] = digB[q][e2] = 0;
     }
-    auto stageC = [&]() {  // land the keys gathered one phase ago
+    auto stageC = [&]() {  // land the digests gathered one phase ago
 #pragma unroll
         for (int q = 0; q < ROUNDS; q++) {
-            int s = q * 64 + lane;
+            const uint32_t wbase = (uint32_t)(q * 64 + lane) * W;
 #pragma unroll
             for (int e = 0; e < D; e++) {
                 uint32_t pos = posB[q] + e;
-                if ((uint32_t)e < cntB[q] && pos >= cur[q]) {
-                    win[(size_t)s * W + pos % W] = ((uint64_t)gB[q][e] << 32) | digB[q][e];
-                }
+                if ((uint32_t)e < cntB[q] && pos >= cur[q]) win[wbase + pos % W] = digB[q][e];
             }
             uint32_t end = posB[q] + cntB[q];
             if (cntB[q] && posB[q] <= landed[q] && end > landed[q]) landed[q] = end;
@@ -151,9 +149,7 @@ __global__ void __launch_bounds__(256, 4)
 #pragma unroll
             for (int e = 0; e < D; e++) {
                 if ((uint32_t)e < cntA[q]) {
-                    uint32_t g = idxA[q][e];
-                    gB[q][e] = g;
-                    digB[q][e] = keys32[2 * (size_t)g + 1];
+                    digB[q][e] = keys32[2 * (size_t)idxA[q][e] + 1];
                 }
             }
             posB[q] = posA[q];
@@ -190,11 +186,15 @@ __global__ void __launch_bounds__(256, 4)
     stageC();
 
     // ---- rejection stream: ring of the top 21 bits of the next draws ----
-    const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
-    const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
-    const Jump j64 = pcg_jump(inc, 64);
-    U128 lane_state = pcg_apply(pcg_jump(inc, (uint64_t)lane + 1), base);  // yields draw `lane`
-    uint64_t gen = 0, c = 0;                                                // draws generated / consumed
+    U128 lane_state;
+    Jump j64;
+    {
+        const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+        const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+        j64 = pcg_jump(inc, 64);
+        lane_state = pcg_apply(pcg_jump(inc, (uint64_t)lane + 1), base);  // yields draw `lane`
+    }
+    uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start
     auto gen_block = [&]() {
         ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43);
         lane_state = pcg_apply(j64, lane_state);
@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(256, 4)
     };
     gen_block();
     gen_block();
+    auto exact53 = [&](uint32_t n_steps) -> uint64_t {  // k53 of the draw that needs n_steps LCG steps from the start
+        const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+        const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+        return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
+    };
 
     // ---- initial-state prefetch: lane i holds the slot of init index ib+i ----
     uint32_t ic = ro.init_cursor[r], ib = ic;
@@ -210,31 +215,45 @@ __global__ void __launch_bounds__(256, 4)
         ib = ic;
         uint32_t k = ic + lane;
         int v = -1;
-        if ((int64_t)k < t.N0) v = t.init_slot[init_row ? init_row[k] : k];
+        if (k < N0) v = t.init_slot[init_row ? init_row[k] : k];
         init_reg = v;
     };
     load_init();
 
     int slot = ro.cur_slot[r];
-    int64_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, cand = 0, len_acc = 0, tt = 0;
+    uint32_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, cand = 0, len_acc = 0, tt = 0;
+    uint32_t n_dry = 0, n_tie = 0, n_flush = 0;
     double sum_g = 0.0, G = 0.0;
     int status = OFFSIM_ST_OK;
-    // per-phase staging: lane i holds reward and discount of the phase's i-th accepted step
-    double r_val = 0.0, gp_val = 0.0;
+    // per-phase log: lane i remembers the phase's i-th accepted step (row, discount exponent[, candidates popped])
+    uint32_t p_log = 0, t_log = 0, pop_log = 0;
     uint64_t done_mask = 0;
-    int nph = 0;
-    uint32_t pop_acc = 0;
+    uint32_t nph = 0, pop_acc = 0;
     const bool r64 = t.r_dtype == OFFSIM_F64;
 
-    auto flush = [&]() {  // in-order discounted-return accumulation (psrs.py:262-269), then the refill pipeline
-        double prod = gp_val * r_val;
-        for (int i = 0; i < nph; i++) {
-            G = G + readlane_f64(prod, i);
+    auto flush = [&]() {  // rewards of the phase, the refill pipeline, then the in-order return accumulation
+        double rv = 0.0, gp = 0.0;
+        if ((uint32_t)lane < nph) {
+            const uint32_t g_log = perm_row ? perm_row[p_log] : p_log;  // accepted row, through the rollout's permutation
+            rv = r64 ? ((const double *)t.r)[g_log] : (double)((const float *)t.r)[g_log];
+            gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
+            if (TRACE) {
+                const uint32_t st = steps - nph + lane;
+                if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + st] = t.orig_idx[g_log];
+                if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + st] = pop_log;
+            }
+        }
+        stageC();
+        stageB();
+        stageA();
+        const double prod = gp * rv;  // psrs.py:262, product first, then the running sum in step order
+        for (uint32_t i = 0; i < nph; i++) {
+            G = G + readlane_f64(prod, (int)i);
             len_acc++;
             if ((done_mask >> i) & 1ull) {
                 if (lane == 0) {
-                    if (out.ep_g && ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
-                    if (out.ep_len && n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
+                    if (out.ep_g && (int64_t)ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
+                    if (out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
                 }
                 sum_g += G;
                 ep_acc++;
@@ -245,16 +264,14 @@ __global__ void __launch_bounds__(256, 4)
         }
         nph = 0;
         done_mask = 0;
-        stageC();
-        stageB();
-        stageA();
+        n_flush++;
     };
 
     bool need_reset = true;  // evalMC_psrs starts every episode with env.reset() (psrs.py:249)
     while (true) {
         if (need_reset) {
             if (ep >= max_episodes) break;
-            if ((int64_t)ic >= t.N0) {  // psrs.py:33-35, 250-252
+            if (ic >= N0) {  // psrs.py:33-35, 250-252
                 status = OFFSIM_ST_NO_INIT;
                 slot = -1;
                 break;
@@ -266,38 +283,72 @@ __global__ void __launch_bounds__(256, 4)
             need_reset = false;
         }
         const int q = slot >> 6, l = slot & 63;
-        const uint32_t len_z = rd_lane<ROUNDS>(len, q, l);
+        uint32_t len_z = 0, cur_z = 0, land_z = 0, beg_z = 0;
+        switch (q) {  // uniform dispatch: static register indices, one v_readlane each
+            case 0:
+                len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[0], l);
+                cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[0], l);
+                land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[0], l);
+                beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[0], l);
+                break;
+            case 1:
+                if constexpr (ROUNDS > 1) {
+                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[1], l);
+                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[1], l);
+                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[1], l);
+                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[1], l);
+                }
+                break;
+            case 2:
+                if constexpr (ROUNDS > 2) {
+                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[2], l);
+                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[2], l);
+                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[2], l);
+                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[2], l);
+                }
+                break;
+            default:
+                if constexpr (ROUNDS > 3) {
+                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[3], l);
+                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[3], l);
+                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[3], l);
+                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[3], l);
+                }
+                break;
+        }
         if (len_z == 0) {  // KeyError (psrs.py:44)
             status = OFFSIM_ST_KEYERROR;
             break;
         }
-        uint32_t cur_z = rd_lane<ROUNDS>(cur, q, l);
-        const uint32_t land_z = rd_lane<ROUNDS>(landed, q, l);
         const uint32_t avail = land_z - cur_z;
         bool accepted = false, slow = (avail == 0);
-        uint32_t acc_dig = 0, acc_g = 0, d = 0;
+        uint32_t acc_dig = 0, acc_p = 0, d = 0;
         if (!slow) {
             const uint32_t nv = avail < (uint32_t)W ? avail : (uint32_t)W;
-            const bool valid = (uint32_t)lane < nv;
-            uint64_t e = 0;
-            if (valid) e = win[(size_t)slot * W + (cur_z + lane) % W];
+            const uint64_t vmask = (1ull << nv) - 1ull;
+            uint32_t wi = cur_z % W + lane;  // ring position of candidate `lane`
+            wi = wi >= (uint32_t)W ? wi - W : wi;
+            uint32_t dig = 0;
+            if (lane < W) dig = win[(uint32_t)slot * W + wi];
             const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
-            const uint32_t dig = (uint32_t)e, Tt = dig >> 11;
-            const uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+            const uint32_t Tt = dig >> 11;
+            const uint64_t macc = __ballot(kt < Tt) & vmask, mamb = __ballot(kt == Tt) & vmask;
             const uint64_t m = macc | mamb;
             if (m == 0) {
                 d = nv;  // every window candidate rejected
             } else {
                 const int f = __ffsll((unsigned long long)m) - 1;
-                if ((mamb >> f) & 1ull) slow = true;  // top-21-bit tie: needs the exact compare
-                else {
+                if ((mamb >> f) & 1ull) {
+                    slow = true;  // top-21-bit tie: needs the exact compare
+                    n_tie++;
+                } else {
                     accepted = true;
                     d = (uint32_t)f + 1;
                     acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
-                    acc_g = (uint32_t)__builtin_amdgcn_readlane((int)(e >> 32), f);
+                    acc_p = beg_z + cur_z + (uint32_t)f;
                 }
             }
-        }
+        } else n_dry++;
         if (slow) {  // window empty or tie: 64 candidates straight from HBM with full keys
             const uint32_t rem = len_z - cur_z;
             if (rem == 0) {  // psrs.py:44-45
@@ -306,7 +357,6 @@ __global__ void __launch_bounds__(256, 4)
             }
             const uint32_t nv = rem < 64u ? rem : 64u;
             const bool valid = (uint32_t)lane < nv;
-            const uint32_t beg_z = rd_lane<ROUNDS>(beg, q, l);
             uint32_t p = beg_z + cur_z + (valid ? lane : 0);
             const uint32_t g = perm_row ? perm_row[p] : p;
             const uint64_t key = keys[g];
@@ -319,7 +369,7 @@ __global__ void __launch_bounds__(256, 4)
                 if (m == 0) break;
                 const int ff = __ffsll((unsigned long long)m) - 1;
                 if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
-                    const uint64_t k53 = exact_draw53(base, inc, c + (uint64_t)ff + 1);
+                    const uint64_t k53 = exact53(c + (uint32_t)ff + 1);
                     const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
                     const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
                     const uint64_t Tf = key_T(((uint64_t)khi << 32) | klo);
@@ -336,33 +386,40 @@ __global__ void __launch_bounds__(256, 4)
                 accepted = true;
                 d = (uint32_t)f + 1;
                 acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
-                acc_g = (uint32_t)__builtin_amdgcn_readlane((int)g, f);
+                acc_p = beg_z + cur_z + (uint32_t)f;
             }
+            // the candidates behind the consumed ones are already in registers: they become the new window
+            const uint32_t keep_end = nv < d + (uint32_t)W ? nv : d + (uint32_t)W;  // lanes [d, keep_end) stay queued
+            if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
+            const uint32_t new_land = cur_z + keep_end;
             cur_z += d;
             wr_lane<ROUNDS>(cur, q, l, cur_z);
             const uint32_t fz = rd_lane<ROUNDS>(fill, q, l);
-            if (land_z < cur_z) wr_lane<ROUNDS>(landed, q, l, cur_z);
-            if (fz < cur_z) wr_lane<ROUNDS>(fill, q, l, cur_z);
+            if (land_z < new_land) wr_lane<ROUNDS>(landed, q, l, new_land);
+            if (fz < new_land) wr_lane<ROUNDS>(fill, q, l, new_land);
         } else {
             cur_z += d;
-            wr_lane<ROUNDS>(cur, q, l, cur_z);
+            switch (q) {
+                case 0: cur[0] = lane == l ? cur_z : cur[0]; break;
+                case 1: if constexpr (ROUNDS > 1) cur[1] = lane == l ? cur_z : cur[1]; break;
+                case 2: if constexpr (ROUNDS > 2) cur[2] = lane == l ? cur_z : cur[2]; break;
+                default: if constexpr (ROUNDS > 3) cur[3] = lane == l ? cur_z : cur[3]; break;
+            }
         }
         c += d;
         cand += d;
-        pop_acc += d;
+        if (TRACE) pop_acc += d;
         while (gen < c + 64) gen_block();
         if (accepted) {
-            if (lane == nph) {
-                r_val = r64 ? ((const double *)t.r)[acc_g] : (double)((const float *)t.r)[acc_g];
-                gp_val = tt < n_gamma_pow ? gamma_pow[tt] : pow_fallback(gamma, (double)tt);
+            const bool mine = (uint32_t)lane == nph;
+            p_log = mine ? acc_p : p_log;
+            t_log = mine ? tt : t_log;
+            if (TRACE) {
+                pop_log = mine ? pop_acc : pop_log;
+                pop_acc = 0;
             }
             const bool dn = (acc_dig >> 10) & 1u;
             if (dn) done_mask |= 1ull << nph;
-            if (TRACE && lane == 0) {
-                if (out.trace_row && steps < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + steps] = t.orig_idx[acc_g];
-                if (out.trace_pop && steps < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + steps] = pop_acc;
-            }
-            pop_acc = 0;
             nph++;
             steps++;
             tt++;
@@ -375,9 +432,10 @@ __global__ void __launch_bounds__(256, 4)
         }
     }
     flush();
-    if (status == OFFSIM_ST_EXHAUSTED && !need_reset) n_len++;  // psrs.py:265: the cut-short episode still logs its length
-    if (status == OFFSIM_ST_EXHAUSTED && !need_reset && lane == 0 && out.ep_len && n_len - 1 <= out.ep_cap)
-        out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len - 1] = (int32_t)len_acc;
+    if (status == OFFSIM_ST_EXHAUSTED && !need_reset) {  // psrs.py:265: the cut-short episode still logs its length
+        if (lane == 0 && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
+        n_len++;
+    }
     // ---- write the env state back ----
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
@@ -388,6 +446,8 @@ __global__ void __launch_bounds__(256, 4)
         ro.init_cursor[r] = ic;
         ro.cur_slot[r] = slot;
         if (c) {
+            const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+            const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
             U128 nb = pcg_apply(pcg_jump(inc, c), base);
             ro.rng[4 * r + 0] = nb.hi;
             ro.rng[4 * r + 1] = nb.lo;
@@ -398,6 +458,12 @@ __global__ void __launch_bounds__(256, 4)
         out.cand[r] = cand;
         out.n_len[r] = n_len;
         out.status[r] = status;
+        if (out.dbg) {
+            out.dbg[4 * (int64_t)r + 0] = n_dry;
+            out.dbg[4 * (int64_t)r + 1] = n_tie;
+            out.dbg[4 * (int64_t)r + 2] = n_flush;
+            out.dbg[4 * (int64_t)r + 3] = gen / 64;
+        }
     }
 }
 

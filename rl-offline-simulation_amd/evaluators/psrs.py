@@ -99,7 +99,7 @@ class BatchedPSRS:
         L.check(L.load().offsim_env_set_state(C.byref(self.state.c), L.ptr(s), L.ptr(m), L.stream_ptr()))
 
     # -- evalMC_psrs (psrs.py:241-271) for all rollouts in one launch --
-    def eval_mc(self, pi_slots, gamma, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096, out=None, fast=None):
+    def eval_mc(self, pi_slots, gamma, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096, out=None, fast=None, dbg=False):
         """pi_slots: [n_slots,nA] policy per state slot (TransitionTable.policy_slots).  Returns a dict of device
         tensors: sum_g, n_ep, steps, cand, n_len, status (+ ep_g, ep_len, trace_row, trace_pop when asked).
         fast=None picks the compiled-policy / LDS-window kernel (offsim_eval_mc_keys) whenever it applies
@@ -122,8 +122,10 @@ class BatchedPSRS:
         if trace_cap:
             o["trace_row"] = torch.full((R, trace_cap), -1, dtype=torch.int32, device=dev)
             o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
+        if dbg:
+            o["dbg"] = torch.zeros((R, 4), dtype=torch.int64, device=dev)
         gp = _gamma_pow(gamma, n_gamma_pow, dev)
-        oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
+        oc = L.EvalMCOut(dbg=L.ptr(o.get("dbg")), sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
                          trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
