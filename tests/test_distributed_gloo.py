@@ -1,0 +1,90 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU exchange step: each rank evaluates every seed on its own
+episode-disjoint shard of the log, one all-reduce(SUM) of [R,2] = (sum of returns, n episodes) combines them
+(SURVEY 8e).  The per-shard evaluator here is the CPU oracle -- on the GPU box the same code path is fed by
+offsim_eval_mc; what is under test is the sharding and the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_inputs(e, mask):
+    return dict(z=e["z"][mask], a=e["actions"][mask], r=e["rewards"][mask], z_next=e["z_next"][mask], done=e["terminals"][mask],
+                p_log=e["action_distributions"][mask], t0=(e["steps"][mask] == 0))
+
+
+def _eval_shard(inp, pi, gamma, seeds):
+    from oracle import oracle as O
+    ora = O.OraclePSRS(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+    est = np.zeros((len(seeds), 2))
+    for i, s in enumerate(seeds):
+        ora.reset_sampler(int(s))
+        res = ora.evalmc(10 ** 9, pi, gamma)
+        est[i] = (res["Gs"].sum(), len(res["Gs"]))
+    return est
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.distributed import allreduce_estimates, combine_value, shard_episodes, shard_rollouts
+    e = synth.synth_iid(6000, 25, 5, seed=4)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = np.arange(12)
+    # (1) log sharded by episode, every seed on every shard, all-reduce of the pairs
+    mask = shard_episodes(e["episode_ids"], rank, world)
+    est = torch.from_numpy(_eval_shard(_shard_inputs(e, mask), pi, 0.99, seeds))
+    allreduce_estimates(est)
+    # (2) rollouts sharded, table replicated: disjoint seed slices, gathered through the same all-reduce
+    lo, hi = shard_rollouts(len(seeds), rank, world)
+    full = torch.zeros((len(seeds), 2), dtype=torch.float64)
+    full[lo:hi] = torch.from_numpy(_eval_shard(_shard_inputs(e, np.ones(len(e["z"]), bool)), pi, 0.99, seeds[lo:hi]))
+    allreduce_estimates(full)
+    if rank == 0:
+        np.savez(tmp, est=est.numpy(), value=combine_value(est).numpy(), full=full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_estimates(tmp_path):
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.distributed import shard_episodes
+    world = 2
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    e = synth.synth_iid(6000, 25, 5, seed=4)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = np.arange(12)
+    masks = [shard_episodes(e["episode_ids"], r, world) for r in range(world)]
+    assert (masks[0] ^ masks[1]).all()  # a partition ...
+    for m in masks:  # ... of whole episodes
+        ids = e["episode_ids"]
+        assert not (set(ids[m]) & set(ids[~m]))
+    want = sum(_eval_shard(_shard_inputs(e, m), pi, 0.99, seeds) for m in masks)
+    assert np.array_equal(got["est"], want)  # SUM all-reduce of f64 pairs, two addends: exact
+    assert np.allclose(got["value"], want[:, 0] / want[:, 1], rtol=0, atol=1e-12)
+    single = _eval_shard(_shard_inputs(e, np.ones(len(e["z"]), bool)), pi, 0.99, seeds)
+    assert np.array_equal(got["full"], single)
+
+
+def test_shard_rollouts_covers_everything():
+    from rl_offline_simulation_amd.distributed import shard_rollouts
+    for n, w in ((4096, 8), (10, 3), (1, 4), (0, 2)):
+        spans = [shard_rollouts(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
