@@ -86,9 +86,15 @@ __device__ __forceinline__ void wr_lane(uint32_t (&v)[ROUNDS], int q, int l, uin
     for (int i = 0; i < ROUNDS; i++) v[i] = (q == i && lane == l) ? val : v[i];
 }
 
-// W = window entries per state, ROUNDS = ceil(n_slots / 64), D = entries requested per state per phase.
-// Everything the chain touches per step is wave-uniform (SGPRs) except the per-state registers, which are
-// read with v_readlane; counters are 32-bit (N < 2^31) to keep the scalar register file from spilling.
+// W = window entries per state, ROUNDS = ceil(n_slots / 64), D = W/2 entries requested per state per phase.
+//
+// The chain loop is written for the scalar unit: one CU has ONE scalar ALU for its 16 rollouts, and the
+// first version of this loop was bound by it (84 SALU instructions per simulated step, rocprofv3 PMC).
+// So the per-state cursor lives in LDS (read as a per-lane value: its arithmetic is VALU), rewards and
+// discount exponents are reconstructed at the phase boundary, and only what is inherently wave-uniform
+// (ballot masks, the draw counter, the current state) stays scalar.
+//
+// LDS per block: [seg_off (n_slots+1) u32, shared] then per wave [win n_slots*W u32][ring 128 u32][meta n_slots x {cur, landed}]
 template <int W, int ROUNDS, bool TRACE>
 __global__ void __launch_bounds__(256, 4)
     k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
@@ -98,9 +104,14 @@ __global__ void __launch_bounds__(256, 4)
     const int waves = blockDim.x / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;  // wave id is uniform: keep it scalar
     const int n_slots = t.n_slots;
-    const uint32_t win_bytes = (uint32_t)n_slots * W * 4;
-    uint32_t *win = (uint32_t *)(lds_raw + (size_t)wave * (win_bytes + OFFSIM_RING * 4));
+    uint32_t *seg = (uint32_t *)lds_raw;
+    const uint32_t seg_bytes = ((uint32_t)(n_slots + 1) * 4 + 15u) & ~15u;
+    const uint32_t win_bytes = (uint32_t)n_slots * W * 4, wave_bytes = win_bytes + OFFSIM_RING * 4 + (uint32_t)n_slots * 8;
+    uint32_t *win = (uint32_t *)(lds_raw + seg_bytes + (size_t)wave * wave_bytes);
     uint32_t *ring = (uint32_t *)((unsigned char *)win + win_bytes);
+    uint2 *meta = (uint2 *)(ring + OFFSIM_RING);  // .x = cur (candidates popped), .y = landed (window valid up to)
+    for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg[i] = t.seg_off[i];
+    __syncthreads();
     const int r = blockIdx.x * waves + wave;
     if (r >= ro.R) return;
 
@@ -112,19 +123,16 @@ __global__ void __launch_bounds__(256, 4)
     const uint32_t n_gamma_pow = (uint32_t)(n_gamma_pow64 > 0x7fffffffll ? 0x7fffffffll : n_gamma_pow64);
     const uint32_t max_episodes = (uint32_t)(max_episodes64 > 0xffffffffll ? 0xffffffffll : max_episodes64);
 
-    // ---- per-state registers: lane l of round q owns state q*64+l ----
-    uint32_t cur[ROUNDS], landed[ROUNDS], fill[ROUNDS], beg[ROUNDS], len[ROUNDS];
+    // ---- refill pipeline registers: lane l of round q owns state q*64+l ----
+    uint32_t fill[ROUNDS];
     uint32_t idxA[ROUNDS][D], posA[ROUNDS], cntA[ROUNDS];
     uint32_t digB[ROUNDS][D], posB[ROUNDS], cntB[ROUNDS];
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
         int s = q * 64 + lane;
-        bool ok = s < n_slots;
-        uint32_t b = ok ? t.seg_off[s] : 0u, e = ok ? t.seg_off[s + 1] : 0u;
-        beg[q] = b;
-        len[q] = e - b;
-        cur[q] = ok ? cur_glb[s] : 0u;
-        landed[q] = fill[q] = cur[q];
+        uint32_t c0 = s < n_slots ? cur_glb[s] : 0u;
+        if (s < n_slots) meta[s] = make_uint2(c0, c0);
+        fill[q] = c0;
         posA[q] = cntA[q] = posB[q] = cntB[q] = 0;
 #pragma unroll
         for (int e2 = 0; e2 < D; e2++) idxA[q][e2] = digB[q][e2] = 0;
@@ -132,26 +140,27 @@ __global__ void __launch_bounds__(256, 4)
     auto stageC = [&]() {  // land the digests gathered one phase ago
 #pragma unroll
         for (int q = 0; q < ROUNDS; q++) {
-            const uint32_t wbase = (uint32_t)(q * 64 + lane) * W;
+            const int s = q * 64 + lane;
+            if (cntB[q]) {  // (implies s < n_slots)
+                const uint2 m = meta[s];
+                const uint32_t wbase = (uint32_t)s * W;
 #pragma unroll
-            for (int e = 0; e < D; e++) {
-                uint32_t pos = posB[q] + e;
-                if ((uint32_t)e < cntB[q] && pos >= cur[q]) win[wbase + pos % W] = digB[q][e];
+                for (int e = 0; e < D; e++) {
+                    uint32_t pos = posB[q] + e;
+                    if ((uint32_t)e < cntB[q] && pos >= m.x) win[wbase + pos % W] = digB[q][e];
+                }
+                const uint32_t end = posB[q] + cntB[q];
+                if (posB[q] <= m.y && end > m.y) meta[s].y = end;
+                cntB[q] = 0;
             }
-            uint32_t end = posB[q] + cntB[q];
-            if (cntB[q] && posB[q] <= landed[q] && end > landed[q]) landed[q] = end;
-            cntB[q] = 0;
         }
     };
     auto stageB = [&]() {  // permutation indices have arrived: gather the digests (high dword of each key)
 #pragma unroll
         for (int q = 0; q < ROUNDS; q++) {
 #pragma unroll
-            for (int e = 0; e < D; e++) {
-                if ((uint32_t)e < cntA[q]) {
-                    digB[q][e] = keys32[2 * (size_t)idxA[q][e] + 1];
-                }
-            }
+            for (int e = 0; e < D; e++)
+                if ((uint32_t)e < cntA[q]) digB[q][e] = keys32[2 * (size_t)idxA[q][e] + 1];
             posB[q] = posA[q];
             cntB[q] = cntA[q];
             cntA[q] = 0;
@@ -160,20 +169,26 @@ __global__ void __launch_bounds__(256, 4)
     auto stageA = [&]() {  // request the next entries of every state's queue
 #pragma unroll
         for (int q = 0; q < ROUNDS; q++) {
-            uint32_t have = fill[q] - cur[q];
-            uint32_t room = have < (uint32_t)W ? (uint32_t)W - have : 0u;
-            uint32_t left = len[q] - fill[q];
-            uint32_t want = room < (uint32_t)D ? room : (uint32_t)D;
-            want = want < left ? want : left;
-            posA[q] = fill[q];
-            cntA[q] = want;
+            const int s = q * 64 + lane;
+            uint32_t want = 0;
+            if (s < n_slots) {
+                const uint32_t cur_s = meta[s].x, beg_s = seg[s], len_s = seg[s + 1] - beg_s;
+                if (fill[q] < cur_s) fill[q] = cur_s;
+                const uint32_t have = fill[q] - cur_s;
+                const uint32_t room = have < (uint32_t)W ? (uint32_t)W - have : 0u;
+                const uint32_t left = len_s - fill[q];
+                want = room < (uint32_t)D ? room : (uint32_t)D;
+                want = want < left ? want : left;
 #pragma unroll
-            for (int e = 0; e < D; e++) {
-                if ((uint32_t)e < want) {
-                    uint32_t p = beg[q] + fill[q] + e;
-                    idxA[q][e] = perm_row ? perm_row[p] : p;
+                for (int e = 0; e < D; e++) {
+                    if ((uint32_t)e < want) {
+                        uint32_t p = beg_s + fill[q] + e;
+                        idxA[q][e] = perm_row ? perm_row[p] : p;
+                    }
                 }
             }
+            posA[q] = fill[q];
+            cntA[q] = want;
             fill[q] += want;
         }
     };
@@ -194,7 +209,7 @@ __global__ void __launch_bounds__(256, 4)
         j64 = pcg_jump(inc, 64);
         lane_state = pcg_apply(pcg_jump(inc, (uint64_t)lane + 1), base);  // yields draw `lane`
     }
-    uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start
+    uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start (every examined candidate = one draw)
     auto gen_block = [&]() {
         ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43);
         lane_state = pcg_apply(j64, lane_state);
@@ -221,12 +236,12 @@ __global__ void __launch_bounds__(256, 4)
     load_init();
 
     int slot = ro.cur_slot[r];
-    uint32_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, cand = 0, len_acc = 0, tt = 0;
+    uint32_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, len_acc = 0, tt0 = 0;
     uint32_t n_dry = 0, n_tie = 0, n_flush = 0;
     double sum_g = 0.0, G = 0.0;
     int status = OFFSIM_ST_OK;
-    // per-phase log: lane i remembers the phase's i-th accepted step (row, discount exponent[, candidates popped])
-    uint32_t p_log = 0, t_log = 0, pop_log = 0;
+    // per-phase log: lane i remembers where the phase's i-th accepted step came from
+    uint32_t pos_log = 0, slot_log = 0, pop_log = 0;
     uint64_t done_mask = 0;
     uint32_t nph = 0, pop_acc = 0;
     const bool r64 = t.r_dtype == OFFSIM_F64;
@@ -234,11 +249,14 @@ __global__ void __launch_bounds__(256, 4)
     auto flush = [&]() {  // rewards of the phase, the refill pipeline, then the in-order return accumulation
         double rv = 0.0, gp = 0.0;
         if ((uint32_t)lane < nph) {
-            const uint32_t g_log = perm_row ? perm_row[p_log] : p_log;  // accepted row, through the rollout's permutation
+            const uint32_t p = seg[slot_log] + pos_log;                // grouped position in this rollout's queue order
+            const uint32_t g_log = perm_row ? perm_row[p] : p;         // accepted row, through the rollout's permutation
             rv = r64 ? ((const double *)t.r)[g_log] : (double)((const float *)t.r)[g_log];
+            const uint64_t below = done_mask & ((1ull << lane) - 1ull);  // episode ends earlier in this phase
+            const uint32_t t_log = below ? (uint32_t)lane - 1u - (63u - (uint32_t)__clzll((long long)below)) : tt0 + (uint32_t)lane;
             gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
             if (TRACE) {
-                const uint32_t st = steps - nph + lane;
+                const uint32_t st = steps + lane;
                 if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + st] = t.orig_idx[g_log];
                 if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + st] = pop_log;
             }
@@ -262,185 +280,144 @@ __global__ void __launch_bounds__(256, 4)
                 len_acc = 0;
             }
         }
+        tt0 = len_acc;
+        steps += nph;
         nph = 0;
         done_mask = 0;
         n_flush++;
     };
 
-    bool need_reset = true;  // evalMC_psrs starts every episode with env.reset() (psrs.py:249)
-    while (true) {
-        if (need_reset) {
-            if (ep >= max_episodes) break;
-            if (ic >= N0) {  // psrs.py:33-35, 250-252
-                status = OFFSIM_ST_NO_INIT;
-                slot = -1;
-                break;
-            }
-            if (ic - ib >= 64) load_init();
-            slot = __builtin_amdgcn_readlane(init_reg, (int)(ic - ib));
-            ic++;
-            tt = 0;
-            need_reset = false;
-        }
-        const int q = slot >> 6, l = slot & 63;
-        uint32_t len_z = 0, cur_z = 0, land_z = 0, beg_z = 0;
-        switch (q) {  // uniform dispatch: static register indices, one v_readlane each
-            case 0:
-                len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[0], l);
-                cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[0], l);
-                land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[0], l);
-                beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[0], l);
-                break;
-            case 1:
-                if constexpr (ROUNDS > 1) {
-                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[1], l);
-                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[1], l);
-                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[1], l);
-                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[1], l);
-                }
-                break;
-            case 2:
-                if constexpr (ROUNDS > 2) {
-                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[2], l);
-                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[2], l);
-                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[2], l);
-                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[2], l);
-                }
-                break;
-            default:
-                if constexpr (ROUNDS > 3) {
-                    len_z = (uint32_t)__builtin_amdgcn_readlane((int)len[3], l);
-                    cur_z = (uint32_t)__builtin_amdgcn_readlane((int)cur[3], l);
-                    land_z = (uint32_t)__builtin_amdgcn_readlane((int)landed[3], l);
-                    beg_z = (uint32_t)__builtin_amdgcn_readlane((int)beg[3], l);
-                }
-                break;
-        }
-        if (len_z == 0) {  // KeyError (psrs.py:44)
-            status = OFFSIM_ST_KEYERROR;
+    while (true) {  // one iteration = one episode (evalMC_psrs: env.reset() then steps until done, psrs.py:246-269)
+        if (ep >= max_episodes) break;
+        if (ic >= N0) {  // psrs.py:33-35, 250-252
+            status = OFFSIM_ST_NO_INIT;
+            slot = -1;
             break;
         }
-        const uint32_t avail = land_z - cur_z;
-        bool accepted = false, slow = (avail == 0);
-        uint32_t acc_dig = 0, acc_p = 0, d = 0;
-        if (!slow) {
-            const uint32_t nv = avail < (uint32_t)W ? avail : (uint32_t)W;
-            const uint64_t vmask = (1ull << nv) - 1ull;
-            uint32_t wi = cur_z % W + lane;  // ring position of candidate `lane`
-            wi = wi >= (uint32_t)W ? wi - W : wi;
-            uint32_t dig = 0;
-            if (lane < W) dig = win[(uint32_t)slot * W + wi];
-            const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
-            const uint32_t Tt = dig >> 11;
-            const uint64_t macc = __ballot(kt < Tt) & vmask, mamb = __ballot(kt == Tt) & vmask;
-            const uint64_t m = macc | mamb;
-            if (m == 0) {
-                d = nv;  // every window candidate rejected
-            } else {
-                const int f = __ffsll((unsigned long long)m) - 1;
-                if ((mamb >> f) & 1ull) {
-                    slow = true;  // top-21-bit tie: needs the exact compare
-                    n_tie++;
+        if (ic - ib >= 64) load_init();
+        slot = __builtin_amdgcn_readlane(init_reg, (int)(ic - ib));
+        ic++;
+        bool dn = false;
+        while (!dn) {  // one iteration = one look at the current state's queue
+            const uint2 m = meta[slot];  // same address in every lane; the arithmetic on it stays on the VALU
+            const uint32_t v_avail = m.y - m.x;
+            bool slow = false, accepted = false;
+            uint32_t acc_dig = 0, acc_pos = 0, d = 0;
+            if (__builtin_amdgcn_readfirstlane(v_avail) != 0) {
+                const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
+                uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
+                wi = wi >= (uint32_t)W ? wi - W : wi;
+                wi = lane < W ? wi : 0u;
+                uint32_t dig = win[(uint32_t)slot * W + wi];
+                dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
+                const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
+                const uint32_t Tt = dig >> 11;
+                const uint64_t many = __ballot(kt <= Tt);
+                if (many == 0) {
+                    d = __builtin_amdgcn_readfirstlane(v_nv);  // every window candidate rejected
+                    meta[slot].x = m.x + d;
                 } else {
-                    accepted = true;
-                    d = (uint32_t)f + 1;
-                    acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
-                    acc_p = beg_z + cur_z + (uint32_t)f;
-                }
-            }
-        } else n_dry++;
-        if (slow) {  // window empty or tie: 64 candidates straight from HBM with full keys
-            const uint32_t rem = len_z - cur_z;
-            if (rem == 0) {  // psrs.py:44-45
-                status = OFFSIM_ST_EXHAUSTED;
-                break;
-            }
-            const uint32_t nv = rem < 64u ? rem : 64u;
-            const bool valid = (uint32_t)lane < nv;
-            uint32_t p = beg_z + cur_z + (valid ? lane : 0);
-            const uint32_t g = perm_row ? perm_row[p] : p;
-            const uint64_t key = keys[g];
-            const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
-            const uint32_t Tt = (uint32_t)(key >> 43);
-            uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
-            int f = -1;
-            while (true) {
-                const uint64_t m = macc | mamb;
-                if (m == 0) break;
-                const int ff = __ffsll((unsigned long long)m) - 1;
-                if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
-                    const uint64_t k53 = exact53(c + (uint32_t)ff + 1);
-                    const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
-                    const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
-                    const uint64_t Tf = key_T(((uint64_t)khi << 32) | klo);
-                    if (k53 > Tf) {
-                        mamb &= ~(1ull << ff);
-                        continue;
+                    const uint64_t macc = __ballot(kt < Tt);
+                    const int f = __ffsll((unsigned long long)many) - 1;
+                    if (!((macc >> f) & 1ull)) {
+                        slow = true;  // top-21-bit tie (or a draw of exactly 0 on an empty lane): exact compare needed
+                        n_tie++;
+                    } else {
+                        accepted = true;
+                        d = (uint32_t)f + 1;
+                        acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
+                        const uint32_t v_pos = m.x + (uint32_t)f;
+                        meta[slot].x = v_pos + 1u;
+                        pos_log = (uint32_t)lane == nph ? v_pos : pos_log;
                     }
                 }
-                f = ff;
-                break;
+            } else {
+                slow = true;
+                n_dry++;
             }
-            if (f < 0) d = nv;
-            else {
-                accepted = true;
-                d = (uint32_t)f + 1;
-                acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
-                acc_p = beg_z + cur_z + (uint32_t)f;
+            if (slow) {  // window empty or tie: 64 candidates straight from HBM with full keys
+                const uint32_t cur_z = __builtin_amdgcn_readfirstlane(m.x), land_z = __builtin_amdgcn_readfirstlane(m.y);
+                const uint32_t beg_z = seg[slot], len_z = seg[slot + 1] - beg_z;
+                if (len_z == 0) {  // KeyError (psrs.py:44)
+                    status = OFFSIM_ST_KEYERROR;
+                    break;
+                }
+                const uint32_t rem = len_z - cur_z;
+                if (rem == 0) {  // psrs.py:44-45
+                    status = OFFSIM_ST_EXHAUSTED;
+                    break;
+                }
+                const uint32_t nv = rem < 64u ? rem : 64u;
+                const bool valid = (uint32_t)lane < nv;
+                const uint32_t p = beg_z + cur_z + (valid ? lane : 0);
+                const uint32_t g = perm_row ? perm_row[p] : p;
+                const uint64_t key = keys[g];
+                const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
+                const uint32_t Tt = (uint32_t)(key >> 43);
+                uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+                int f = -1;
+                while (true) {
+                    const uint64_t mm = macc | mamb;
+                    if (mm == 0) break;
+                    const int ff = __ffsll((unsigned long long)mm) - 1;
+                    if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
+                        const uint64_t k53 = exact53(c + (uint32_t)ff + 1);
+                        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
+                        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
+                        if (k53 > key_T(((uint64_t)khi << 32) | klo)) {
+                            mamb &= ~(1ull << ff);
+                            continue;
+                        }
+                    }
+                    f = ff;
+                    break;
+                }
+                if (f < 0) d = nv;
+                else {
+                    accepted = true;
+                    d = (uint32_t)f + 1;
+                    acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
+                    acc_pos = cur_z + (uint32_t)f;
+                    pos_log = (uint32_t)lane == nph ? acc_pos : pos_log;
+                }
+                // the candidates behind the consumed ones are already in registers: they become the new window
+                const uint32_t keep_end = nv < d + (uint32_t)W ? nv : d + (uint32_t)W;  // lanes [d, keep_end) stay queued
+                if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
+                const uint32_t new_land = cur_z + keep_end;
+                meta[slot] = make_uint2(cur_z + d, land_z < new_land ? new_land : land_z);
             }
-            // the candidates behind the consumed ones are already in registers: they become the new window
-            const uint32_t keep_end = nv < d + (uint32_t)W ? nv : d + (uint32_t)W;  // lanes [d, keep_end) stay queued
-            if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
-            const uint32_t new_land = cur_z + keep_end;
-            cur_z += d;
-            wr_lane<ROUNDS>(cur, q, l, cur_z);
-            const uint32_t fz = rd_lane<ROUNDS>(fill, q, l);
-            if (land_z < new_land) wr_lane<ROUNDS>(landed, q, l, new_land);
-            if (fz < new_land) wr_lane<ROUNDS>(fill, q, l, new_land);
-        } else {
-            cur_z += d;
-            switch (q) {
-                case 0: cur[0] = lane == l ? cur_z : cur[0]; break;
-                case 1: if constexpr (ROUNDS > 1) cur[1] = lane == l ? cur_z : cur[1]; break;
-                case 2: if constexpr (ROUNDS > 2) cur[2] = lane == l ? cur_z : cur[2]; break;
-                default: if constexpr (ROUNDS > 3) cur[3] = lane == l ? cur_z : cur[3]; break;
+            c += d;
+            if (TRACE) pop_acc += d;
+            while (gen < c + 64) gen_block();
+            if (accepted) {
+                const bool mine = (uint32_t)lane == nph;
+                slot_log = mine ? (uint32_t)slot : slot_log;
+                if (TRACE) {
+                    pop_log = mine ? pop_acc : pop_log;
+                    pop_acc = 0;
+                }
+                dn = (acc_dig >> 10) & 1u;
+                done_mask |= (uint64_t)dn << nph;
+                nph++;
+                slot = (int)(acc_dig & 1023u);
+                if (nph == OFFSIM_PH) flush();
             }
         }
-        c += d;
-        cand += d;
-        if (TRACE) pop_acc += d;
-        while (gen < c + 64) gen_block();
-        if (accepted) {
-            const bool mine = (uint32_t)lane == nph;
-            p_log = mine ? acc_p : p_log;
-            t_log = mine ? tt : t_log;
-            if (TRACE) {
-                pop_log = mine ? pop_acc : pop_log;
-                pop_acc = 0;
-            }
-            const bool dn = (acc_dig >> 10) & 1u;
-            if (dn) done_mask |= 1ull << nph;
-            nph++;
-            steps++;
-            tt++;
-            slot = (int)(acc_dig & 1023u);
-            if (dn) {
-                ep++;
-                need_reset = true;
-            }
-            if (nph == OFFSIM_PH) flush();
-        }
+        if (status != OFFSIM_ST_OK) break;
+        ep++;
     }
+    const bool mid_episode = (status == OFFSIM_ST_EXHAUSTED);  // the step loop only stops inside an episode
     flush();
-    if (status == OFFSIM_ST_EXHAUSTED && !need_reset) {  // psrs.py:265: the cut-short episode still logs its length
+    if (mid_episode) {  // psrs.py:265: the cut-short episode still logs its length
         if (lane == 0 && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
         n_len++;
     }
     // ---- write the env state back ----
+    __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
         int s = q * 64 + lane;
-        if (s < n_slots) cur_glb[s] = cur[q];
+        if (s < n_slots) cur_glb[s] = meta[s].x;
     }
     if (lane == 0) {
         ro.init_cursor[r] = ic;
@@ -455,7 +432,7 @@ __global__ void __launch_bounds__(256, 4)
         out.sum_g[r] = sum_g;
         out.n_ep[r] = ep_acc;
         out.steps[r] = steps;
-        out.cand[r] = cand;
+        out.cand[r] = c;
         out.n_len[r] = n_len;
         out.status[r] = status;
         if (out.dbg) {
