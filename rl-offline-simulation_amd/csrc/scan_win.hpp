@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256, 4)
     load_init();
 
     int slot = ro.cur_slot[r];
-    uint32_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, len_acc = 0, tt0 = 0;
+    uint32_t ep = 0, ep_acc = 0, n_len = 0, steps = 0, len_acc = 0;
     uint32_t n_dry = 0, n_tie = 0, n_flush = 0;
     double sum_g = 0.0, G = 0.0;
     int status = OFFSIM_ST_OK;
@@ -246,151 +246,205 @@ __global__ void __launch_bounds__(256, 4)
     uint32_t nph = 0, pop_acc = 0;
     const bool r64 = t.r_dtype == OFFSIM_F64;
 
-    auto flush = [&]() {  // rewards of the phase, the refill pipeline, then the in-order return accumulation
-        double rv = 0.0, gp = 0.0;
-        if ((uint32_t)lane < nph) {
-            const uint32_t p = seg[slot_log] + pos_log;                // grouped position in this rollout's queue order
-            const uint32_t g_log = perm_row ? perm_row[p] : p;         // accepted row, through the rollout's permutation
-            rv = r64 ? ((const double *)t.r)[g_log] : (double)((const float *)t.r)[g_log];
-            const uint64_t below = done_mask & ((1ull << lane) - 1ull);  // episode ends earlier in this phase
-            const uint32_t t_log = below ? (uint32_t)lane - 1u - (63u - (uint32_t)__clzll((long long)below)) : tt0 + (uint32_t)lane;
-            gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
-            if (TRACE) {
-                const uint32_t st = steps + lane;
-                if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + st] = t.orig_idx[g_log];
-                if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + st] = pop_log;
+    // Reward pipeline, three phases deep so that no phase boundary waits on HBM:
+    //   R1 (phase k ends):   issue g = perm[p] and gamma**t for the phase's accepted steps
+    //   R2 (one phase later): issue r[g]        R3 (two phases later): accumulate returns in step order
+    uint32_t g1 = 0;                     // R1 -> R2
+    double gp1 = 0.0, gp2 = 0.0, rv2 = 0.0;  // R1 -> R2 -> R3
+    uint32_t pop1 = 0;
+    uint64_t dm1 = 0, dm2 = 0;
+    uint32_t n1 = 0, n2 = 0, st1 = 0;
+    uint32_t tt_chain = 0;               // accepted steps since the last episode end, as of the end of the last logged phase
+    auto flush = [&]() {
+        // ---- uses first: everything consumed here was requested at least one phase ago ----
+        {   // R3: in-order discounted-return accumulation (psrs.py:262-269)
+            const double prod = gp2 * rv2;  // product first, then the running sum in step order
+            for (uint32_t i = 0; i < n2; i++) {
+                G = G + readlane_f64(prod, (int)i);
+                len_acc++;
+                if ((dm2 >> i) & 1ull) {
+                    if (lane == 0) {
+                        if (out.ep_g && (int64_t)ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
+                        if (out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
+                    }
+                    sum_g += G;
+                    ep_acc++;
+                    n_len++;
+                    G = 0.0;
+                    len_acc = 0;
+                }
             }
         }
         stageC();
+        // ---- then the new requests ----
+        {   // R2
+            double rv = 0.0;
+            if ((uint32_t)lane < n1) {
+                rv = r64 ? ((const double *)t.r)[g1] : (double)((const float *)t.r)[g1];
+                if (TRACE) {
+                    const uint32_t st = st1 + lane;
+                    if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + st] = t.orig_idx[g1];
+                    if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + st] = pop1;
+                }
+            }
+            rv2 = rv;
+            gp2 = gp1;
+            dm2 = dm1;
+            n2 = n1;
+        }
         stageB();
         stageA();
-        const double prod = gp * rv;  // psrs.py:262, product first, then the running sum in step order
-        for (uint32_t i = 0; i < nph; i++) {
-            G = G + readlane_f64(prod, (int)i);
-            len_acc++;
-            if ((done_mask >> i) & 1ull) {
-                if (lane == 0) {
-                    if (out.ep_g && (int64_t)ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
-                    if (out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
-                }
-                sum_g += G;
-                ep_acc++;
-                n_len++;
-                G = 0.0;
-                len_acc = 0;
+        {   // R1
+            uint32_t g = 0;
+            double gp = 0.0;
+            if ((uint32_t)lane < nph) {
+                const uint32_t p = seg[slot_log] + pos_log;  // grouped position in this rollout's queue order
+                g = perm_row ? perm_row[p] : p;              // accepted row, through the rollout's permutation
+                const uint64_t below = done_mask & ((1ull << lane) - 1ull);  // episode ends earlier in this phase
+                const uint32_t t_log = below ? (uint32_t)lane - 1u - (63u - (uint32_t)__clzll((long long)below)) : tt_chain + (uint32_t)lane;
+                gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
             }
+            g1 = g;
+            gp1 = gp;
+            pop1 = pop_log;
+            dm1 = done_mask;
+            n1 = nph;
+            st1 = steps;
+            tt_chain = done_mask ? nph - 1u - (63u - (uint32_t)__clzll((long long)done_mask)) : tt_chain + nph;
+            steps += nph;
+            nph = 0;
+            done_mask = 0;
         }
-        tt0 = len_acc;
-        steps += nph;
-        nph = 0;
-        done_mask = 0;
         n_flush++;
     };
 
-    while (true) {  // one iteration = one episode (evalMC_psrs: env.reset() then steps until done, psrs.py:246-269)
-        if (ep >= max_episodes) break;
-        if (ic >= N0) {  // psrs.py:33-35, 250-252
-            status = OFFSIM_ST_NO_INIT;
-            slot = -1;
-            break;
+    // ---- the chain ----
+    // Written as a straight-line fast loop (accept from the window) that leaves through ONE rarely-taken branch per
+    // kind of event; a single wave pays ~10 cycles per dependent instruction and ~25 per taken branch, so the shape of
+    // this loop, not memory, sets the kernel time.
+    enum { EV_DRY = 0, EV_TIE = 1, EV_ALLREJ = 2, EV_MISC = 3 };
+    bool need_reset = true, dn = false;
+    uint2 m = make_uint2(0u, 0u);
+    uint32_t kt = 0;
+    for (;;) {
+        if (need_reset) {  // env.reset() at the start of every episode (psrs.py:249)
+            if (ep >= max_episodes) break;
+            if (ic >= N0) {  // psrs.py:33-35, 250-252
+                status = OFFSIM_ST_NO_INIT;
+                slot = -1;
+                break;
+            }
+            if (ic - ib >= 64) load_init();
+            slot = __builtin_amdgcn_readlane(init_reg, (int)(ic - ib));
+            ic++;
+            need_reset = false;
+            dn = false;
+            m = meta[slot];
+            kt = ring[(c + lane) & (OFFSIM_RING - 1)];
         }
-        if (ic - ib >= 64) load_init();
-        slot = __builtin_amdgcn_readlane(init_reg, (int)(ic - ib));
-        ic++;
-        bool dn = false;
-        while (!dn) {  // one iteration = one look at the current state's queue
-            const uint2 m = meta[slot];  // same address in every lane; the arithmetic on it stays on the VALU
+        int ev;
+        for (;;) {  // fast loop: one iteration = one accepted step served from the LDS window
             const uint32_t v_avail = m.y - m.x;
-            bool slow = false, accepted = false;
-            uint32_t acc_dig = 0, acc_pos = 0, d = 0;
-            if (__builtin_amdgcn_readfirstlane(v_avail) != 0) {
-                const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
-                uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
-                wi = wi >= (uint32_t)W ? wi - W : wi;
-                wi = lane < W ? wi : 0u;
-                uint32_t dig = win[(uint32_t)slot * W + wi];
-                dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
-                const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
-                const uint32_t Tt = dig >> 11;
-                const uint64_t many = __ballot(kt <= Tt);
-                if (many == 0) {
-                    d = __builtin_amdgcn_readfirstlane(v_nv);  // every window candidate rejected
-                    meta[slot].x = m.x + d;
-                } else {
-                    const uint64_t macc = __ballot(kt < Tt);
-                    const int f = __ffsll((unsigned long long)many) - 1;
-                    if (!((macc >> f) & 1ull)) {
-                        slow = true;  // top-21-bit tie (or a draw of exactly 0 on an empty lane): exact compare needed
-                        n_tie++;
-                    } else {
-                        accepted = true;
-                        d = (uint32_t)f + 1;
-                        acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
-                        const uint32_t v_pos = m.x + (uint32_t)f;
-                        meta[slot].x = v_pos + 1u;
-                        pos_log = (uint32_t)lane == nph ? v_pos : pos_log;
-                    }
-                }
-            } else {
-                slow = true;
-                n_dry++;
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(v_avail) == 0, 0)) {
+                ev = EV_DRY;
+                break;
             }
-            if (slow) {  // window empty or tie: 64 candidates straight from HBM with full keys
-                const uint32_t cur_z = __builtin_amdgcn_readfirstlane(m.x), land_z = __builtin_amdgcn_readfirstlane(m.y);
-                const uint32_t beg_z = seg[slot], len_z = seg[slot + 1] - beg_z;
-                if (len_z == 0) {  // KeyError (psrs.py:44)
-                    status = OFFSIM_ST_KEYERROR;
-                    break;
-                }
-                const uint32_t rem = len_z - cur_z;
-                if (rem == 0) {  // psrs.py:44-45
-                    status = OFFSIM_ST_EXHAUSTED;
-                    break;
-                }
-                const uint32_t nv = rem < 64u ? rem : 64u;
-                const bool valid = (uint32_t)lane < nv;
-                const uint32_t p = beg_z + cur_z + (valid ? lane : 0);
-                const uint32_t g = perm_row ? perm_row[p] : p;
-                const uint64_t key = keys[g];
-                const uint32_t kt = ring[(c + lane) & (OFFSIM_RING - 1)];
-                const uint32_t Tt = (uint32_t)(key >> 43);
-                uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
-                int f = -1;
-                while (true) {
-                    const uint64_t mm = macc | mamb;
-                    if (mm == 0) break;
-                    const int ff = __ffsll((unsigned long long)mm) - 1;
-                    if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
-                        const uint64_t k53 = exact53(c + (uint32_t)ff + 1);
-                        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
-                        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
-                        if (k53 > key_T(((uint64_t)khi << 32) | klo)) {
-                            mamb &= ~(1ull << ff);
-                            continue;
-                        }
-                    }
-                    f = ff;
-                    break;
-                }
-                if (f < 0) d = nv;
-                else {
-                    accepted = true;
-                    d = (uint32_t)f + 1;
-                    acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
-                    acc_pos = cur_z + (uint32_t)f;
-                    pos_log = (uint32_t)lane == nph ? acc_pos : pos_log;
-                }
-                // the candidates behind the consumed ones are already in registers: they become the new window
-                const uint32_t keep_end = nv < d + (uint32_t)W ? nv : d + (uint32_t)W;  // lanes [d, keep_end) stay queued
-                if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
-                const uint32_t new_land = cur_z + keep_end;
-                meta[slot] = make_uint2(cur_z + d, land_z < new_land ? new_land : land_z);
+            const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
+            uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
+            wi = wi >= (uint32_t)W ? wi - W : wi;
+            wi = lane < W ? wi : 0u;
+            uint32_t dig = win[(uint32_t)slot * W + wi];
+            dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
+            const uint32_t Tt = dig >> 11;
+            const uint64_t many = __ballot(kt <= Tt);
+            if (__builtin_expect(many == 0, 0)) {
+                ev = EV_ALLREJ;
+                break;
             }
+            const uint64_t macc = __ballot(kt < Tt);
+            const int f = __ffsll((unsigned long long)many) - 1;
+            if (__builtin_expect(!((macc >> f) & 1ull), 0)) {
+                ev = EV_TIE;  // top-21-bit tie (or a draw of exactly 0 on an empty lane): exact compare needed
+                break;
+            }
+            const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
+            const uint32_t v_pos = m.x + (uint32_t)f;
+            meta[slot].x = v_pos + 1u;
+            const bool mine = (uint32_t)lane == nph;
+            pos_log = mine ? v_pos : pos_log;
+            slot_log = mine ? (uint32_t)slot : slot_log;
+            c += (uint32_t)f + 1u;
+            if (TRACE) {
+                pop_log = mine ? pop_acc + (uint32_t)f + 1u : pop_log;
+                pop_acc = 0;
+            }
+            dn = (acc_dig >> 10) & 1u;
+            done_mask |= (uint64_t)dn << nph;
+            nph++;
+            slot = (int)(acc_dig & 1023u);
+            kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
+            m = meta[slot];                            // and the next state
+            if (__builtin_expect((uint32_t)dn | (uint32_t)(nph == OFFSIM_PH) | (uint32_t)(gen - c < 64u), 0)) {
+                ev = EV_MISC;
+                break;
+            }
+        }
+        if (ev == EV_ALLREJ) {  // every window candidate rejected: consume them, look again
+            const uint32_t v_avail = m.y - m.x;
+            const uint32_t d = __builtin_amdgcn_readfirstlane(v_avail < (uint32_t)W ? v_avail : (uint32_t)W);
+            meta[slot].x = m.x + d;
             c += d;
             if (TRACE) pop_acc += d;
-            while (gen < c + 64) gen_block();
-            if (accepted) {
+        } else if (ev == EV_DRY || ev == EV_TIE) {  // 64 candidates straight from HBM with full keys
+            if (ev == EV_DRY) n_dry++;
+            else n_tie++;
+            const uint32_t cur_z = __builtin_amdgcn_readfirstlane(m.x), land_z = __builtin_amdgcn_readfirstlane(m.y);
+            const uint32_t beg_z = seg[slot], len_z = seg[slot + 1] - beg_z;
+            if (len_z == 0) {  // KeyError (psrs.py:44)
+                status = OFFSIM_ST_KEYERROR;
+                break;
+            }
+            const uint32_t rem = len_z - cur_z;
+            if (rem == 0) {  // psrs.py:44-45
+                status = OFFSIM_ST_EXHAUSTED;
+                break;
+            }
+            const uint32_t nv = rem < 64u ? rem : 64u;
+            const bool valid = (uint32_t)lane < nv;
+            const uint32_t p = beg_z + cur_z + (valid ? lane : 0);
+            const uint32_t g = perm_row ? perm_row[p] : p;
+            const uint64_t key = keys[g];
+            const uint32_t Tt = (uint32_t)(key >> 43);
+            uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+            int f = -1;
+            while (true) {
+                const uint64_t mm = macc | mamb;
+                if (mm == 0) break;
+                const int ff = __ffsll((unsigned long long)mm) - 1;
+                if ((mamb >> ff) & 1ull) {  // exact: k53 of draw c+ff against the full T
+                    const uint64_t k53 = exact53(c + (uint32_t)ff + 1);
+                    const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, ff);
+                    const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), ff);
+                    if (k53 > key_T(((uint64_t)khi << 32) | klo)) {
+                        mamb &= ~(1ull << ff);
+                        continue;
+                    }
+                }
+                f = ff;
+                break;
+            }
+            const uint32_t d = f < 0 ? nv : (uint32_t)f + 1u;
+            // the candidates behind the consumed ones are already in registers: they become the new window
+            const uint32_t keep_end = nv < d + (uint32_t)W ? nv : d + (uint32_t)W;  // lanes [d, keep_end) stay queued
+            if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
+            const uint32_t new_land = cur_z + keep_end;
+            meta[slot] = make_uint2(cur_z + d, land_z < new_land ? new_land : land_z);
+            c += d;
+            if (TRACE) pop_acc += d;
+            if (f >= 0) {
+                const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
                 const bool mine = (uint32_t)lane == nph;
+                pos_log = mine ? cur_z + (uint32_t)f : pos_log;
                 slot_log = mine ? (uint32_t)slot : slot_log;
                 if (TRACE) {
                     pop_log = mine ? pop_acc : pop_log;
@@ -400,13 +454,22 @@ __global__ void __launch_bounds__(256, 4)
                 done_mask |= (uint64_t)dn << nph;
                 nph++;
                 slot = (int)(acc_dig & 1023u);
-                if (nph == OFFSIM_PH) flush();
             }
         }
-        if (status != OFFSIM_ST_OK) break;
-        ep++;
+        // ---- common tail of every event: draws, phase boundary, episode end, refreshed prefetch ----
+        while (gen < c + 64) gen_block();
+        if (nph == OFFSIM_PH) flush();
+        if (dn) {
+            ep++;
+            need_reset = true;
+        } else {
+            m = meta[slot];
+            kt = ring[(c + lane) & (OFFSIM_RING - 1)];
+        }
     }
     const bool mid_episode = (status == OFFSIM_ST_EXHAUSTED);  // the step loop only stops inside an episode
+    flush();
+    flush();  // drain the reward pipeline (R2, R3 of the last phases)
     flush();
     if (mid_episode) {  // psrs.py:265: the cut-short episode still logs its length
         if (lane == 0 && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
