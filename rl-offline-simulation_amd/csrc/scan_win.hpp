@@ -344,11 +344,7 @@ __global__ void __launch_bounds__(256, 4)
         }
         int ev;
         for (;;) {  // fast loop: one iteration = one accepted step served from the LDS window
-            const uint32_t v_avail = m.y - m.x;
-            if (__builtin_expect(__builtin_amdgcn_readfirstlane(v_avail) == 0, 0)) {
-                ev = EV_DRY;
-                break;
-            }
+            const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop leaves as "all rejected"
             const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
             uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
             wi = wi >= (uint32_t)W ? wi - W : wi;
@@ -384,11 +380,13 @@ __global__ void __launch_bounds__(256, 4)
             slot = (int)(acc_dig & 1023u);
             kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
             m = meta[slot];                            // and the next state
-            if (__builtin_expect((uint32_t)dn | (uint32_t)(nph == OFFSIM_PH) | (uint32_t)(gen - c < 64u), 0)) {
+            // one scalar test for the three rare events: episode end | 64 steps logged | fewer than 64 draws left
+            if (__builtin_expect((((acc_dig >> 10) & 1u) | (nph >> 6) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
                 ev = EV_MISC;
                 break;
             }
         }
+        if (ev == EV_ALLREJ && __builtin_amdgcn_readfirstlane(m.y - m.x) == 0u) ev = EV_DRY;
         if (ev == EV_ALLREJ) {  // every window candidate rejected: consume them, look again
             const uint32_t v_avail = m.y - m.x;
             const uint32_t d = __builtin_amdgcn_readfirstlane(v_avail < (uint32_t)W ? v_avail : (uint32_t)W);
