@@ -172,7 +172,7 @@ def main():
             "value_estimate_mean": float(np.nanmean(vest)),
             "scan_only_steps_per_s": my_steps * a.steps / t_scan, "reset_sampler_s_per_pass": t_reset / a.steps,
             "scan_s_per_pass": t_scan / a.steps,
-            "roofline": {"bound": "hbm", "kernel": "k_eval_mc", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_eval_mc_win (offsim_eval_mc_keys)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes_pass / max(n_scan / a.steps, 1),
                          "bytes_per_candidate": b_c, "bytes_per_step": b_s, "launches": n_scan,
