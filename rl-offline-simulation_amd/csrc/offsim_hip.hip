@@ -838,12 +838,49 @@ __global__ void __launch_bounds__(256) k_encode_mlp(const XT *__restrict__ x, in
         out_z[row] = best;
     }
 }
+#include "encode_mfma.hpp"
+
+template <typename XT>
+static int launch_mlp_mfma(const XT *x, int64_t N, int dO, const float *W1, const float *b1, int H, const float *W2, const float *b2,
+                           int nZ, int32_t *out_z, float *out_logits, hipStream_t st) {
+    const int HT = (H + 31) / 32, ZT = (nZ + 31) / 32;
+    const int dOp = (dO + 1) & ~1;
+    size_t lds = sizeof(float) * ((size_t)HT * 32 * (dOp + 1) + (size_t)ZT * 32 * (HT * 32 + 1) + HT * 32 + ZT * 32);
+    if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: weights exceed LDS%s");
+    int64_t groups = (N + 31) / 32;
+    unsigned nb = (unsigned)((groups + 3) / 4);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+#define LAUNCH_MFMA(HTc, ZTc)                                                                                              \
+    do {                                                                                                                   \
+        if (lds > 64 * 1024)                                                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp_mfma<XT, HTc, ZTc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_encode_mlp_mfma<XT, HTc, ZTc>), dim3(nb), dim3(256), lds, st, x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits); \
+    } while (0)
+    if (HT == 1 && ZT == 1) LAUNCH_MFMA(1, 1);
+    else if (HT == 2 && ZT == 1) LAUNCH_MFMA(2, 1);
+    else if (HT == 2 && ZT == 2) LAUNCH_MFMA(2, 2);
+    else if (HT == 1 && ZT == 2) LAUNCH_MFMA(1, 2);
+    else if (HT == 4 && ZT == 1) LAUNCH_MFMA(4, 1);
+    else if (HT == 4 && ZT == 2) LAUNCH_MFMA(4, 2);
+    else return 1;  // shape outside the MFMA instantiations: caller falls back to the VALU kernel
+#undef LAUNCH_MFMA
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 extern "C" int offsim_encode_mlp(const void *x, int32_t x_dtype, int64_t N, int32_t dO, const float *W1, const float *b1,
                                  int32_t H, const float *W2, const float *b2, int32_t nZ, int32_t *out_z, float *out_logits,
                                  void *stream) {
     if (N < 0 || dO <= 0 || H <= 0 || nZ <= 0 || !W1 || !b1 || !W2 || !b2) return fail(OFFSIM_EINVAL, "encode_mlp: bad argument%s");
     if (H > MLP_MAX_H) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: hidden size > 128%s");
     if (N == 0) return OFFSIM_OK;
+    {   // matrix-core path for the shapes the reference uses (H <= 128, nZ <= 64); VALU kernel otherwise
+        int rc = 1;
+        if (x_dtype == OFFSIM_F32) rc = launch_mlp_mfma<float>((const float *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits, (hipStream_t)stream);
+        else if (x_dtype == OFFSIM_F16) rc = launch_mlp_mfma<__half>((const __half *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     size_t lds = sizeof(float) * ((size_t)H * dO + H + (size_t)nZ * H + nZ);
     if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: weights exceed LDS%s");
     unsigned nb = (unsigned)((N + 255) / 256);
