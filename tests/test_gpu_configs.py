@@ -1,0 +1,134 @@
+"""BASELINE.json configs at parity-test scale, end to end on the device (encoder -> table -> sampler -> evalMC),
+each checked against the CPU oracle fed with the same latent states."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    return torch.device("cuda", 0)
+
+
+def _check_against_oracle(e, z, z_next, pi, gamma, seeds, gpu, r_dtype=np.float64):
+    from oracle import oracle as O
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    t0 = e["steps"] == 0
+    r = e["rewards"].astype(r_dtype)
+    table = TransitionTable(z, e["actions"], r, z_next, e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds)
+    o = env.eval_mc(table.policy_slots(pi), gamma, trace_cap=len(z))
+    torch.cuda.synchronize()
+    ora = O.OraclePSRS(z, e["actions"], r, z_next, e["terminals"], e["action_distributions"], t0)
+    for i, s in enumerate(seeds):
+        ora.reset_sampler(s)
+        try:
+            ref = ora.evalmc(10 ** 9, pi, gamma, trace_cap=len(z))
+        except KeyError:
+            assert int(o["status"][i]) == 3
+            continue
+        n = ref["steps"]
+        assert int(o["steps"][i]) == n and int(o["cand"][i]) == ref["candidates"]
+        assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])  # accepted-index sequence, bit-exact
+        if len(ref["Gs"]):
+            assert abs(float(o["sum_g"][i]) / int(o["n_ep"][i]) - ref["Gs"].mean()) <= 1e-5
+    return table, o
+
+
+def test_c1_c2_cartpole_box_encoder(gpu):
+    """C1/C2 shape: CartPole dynamics log, device box encoder (163 slots incl. z = -1), tabular pi over boxes."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+    e = synth.cartpole_log(200_000, seed=5)
+    enc = CartpoleBoxEncoder()
+    z, zn = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+    assert np.array_equal(z, O.cartpole_encode(e["observations"])) and np.array_equal(zn, O.cartpole_encode(e["next_observations"]))
+    assert zn.min() == -1
+    pi = synth.dirichlet_policy(162, 2)
+    table, o = _check_against_oracle(e, z, zn, pi, 0.99, list(range(16)), gpu)
+    assert table.z_base == -1 and 100 < table.n_slots <= 163
+
+
+def test_c3_continuous_grid_learned_encoder(gpu):
+    """C3 shape: continuous grid observations, 2 -> 64 -> 25 encoder forward on MFMA, then PSRS on the encoded states."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.encoders import HOMEREncoder
+    e = synth.grid_coords_log_fast(300_000, seed=3, n_envs=512)
+    g = np.random.default_rng(7)
+    W1, b1 = g.standard_normal((64, 2)).astype(np.float32), g.standard_normal(64).astype(np.float32)
+    W2, b2 = g.standard_normal((25, 64)).astype(np.float32) / 8, g.standard_normal(25).astype(np.float32) * 0.1
+    enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
+                                                 "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2})
+    z, zn = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+    zo, lo = O.mlp_encode(e["observations"], W1, b1, W2, b2)
+    top2 = np.sort(lo, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+    assert np.array_equal(z[clear], zo[clear]) and clear.mean() > 0.999
+    pi = synth.dirichlet_policy(25, 5)
+    _check_against_oracle(e, z, zn, pi, 0.95, list(range(8)), gpu)
+
+
+def test_c5_fp16_buffer(gpu):
+    """C5 shape: fp16 logging probabilities (and fp16 observations through the encoder): the oracle consumes the
+    fp16-rounded values, the device widens them exactly."""
+    from rl_offline_simulation_amd import synth
+    e = synth.synth_iid(100_000, 50, 4, seed=8)
+    p16 = e["action_distributions"].astype(np.float16)
+    e16 = dict(e, action_distributions=p16)
+    pi = synth.dirichlet_policy(50, 4)
+    from oracle import oracle as O
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], p16, t0, device=gpu)
+    assert table.p_log.dtype == torch.float16 and table.bytes_per_candidate == 4 * 2 + 4
+    seeds = [3, 4, 5, 6]
+    for fast in (True, False):
+        env = BatchedPSRS(table, len(seeds))
+        env.reset_sampler(seeds)
+        o = env.eval_mc(table.policy_slots(pi), 0.99, trace_cap=100_000, fast=fast)
+        torch.cuda.synchronize()
+        ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], p16.astype(np.float64), t0)
+        for i, s in enumerate(seeds):
+            ora.reset_sampler(s)
+            ref = ora.evalmc(10 ** 9, pi, 0.99, trace_cap=100_000)
+            n = ref["steps"]
+            assert int(o["steps"][i]) == n
+            assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])
+
+
+def test_evalmc_psrs_drop_in_function(gpu):
+    """evalMC_psrs(env, n_episodes, pi, gamma) on the drop-in PSRS class returns the reference's (Gs, lengths)."""
+    from common import load
+    from rl_offline_simulation_amd.evaluators import PSRS, evalMC_psrs
+    d = load("iid_2k_s25_a5")
+    env = PSRS.from_arrays(d["in_z"], d["in_a"], d["in_r"], d["in_z_next"], d["in_done"], d["in_p_log"], d["in_t0"])
+    for s in d["seeds"]:
+        s = int(s)
+        env.reset_sampler(s)
+        Gs, lengths = evalMC_psrs(env, 10 ** 9, d["pi"], float(d["gamma"]))
+        assert np.array_equal(Gs, d[f"s{s}_mc_Gs"]) and np.array_equal(lengths, d[f"s{s}_mc_lengths"])
+    env.reset_sampler(0)
+    Gs, lengths = evalMC_psrs(env, 1, d["pi"], float(d["gamma"]))  # episode cap
+    assert np.array_equal(Gs, d["s0_mc_Gs"][:1]) and np.array_equal(lengths, d["s0_mc_lengths"][:1])
+
+
+def test_evalmc_rollouts_tiled_equals_untiled(gpu):
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import evalmc_rollouts
+    e = synth.synth_iid(50_000, 30, 3, seed=2)
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi = synth.dirichlet_policy(30, 3)
+    a = evalmc_rollouts(table, range(24), pi, 0.9)
+    b = evalmc_rollouts(table, range(24), pi, 0.9, tile=7)
+    for k in ("sum_g", "n_ep", "steps", "cand", "status"):
+        assert np.array_equal(a[k], b[k])
