@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--transitions", type=int, default=10_000_000, help="logged transitions per GPU")
     ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts) per GPU")
+    ap.add_argument("--workload", default="iid", choices=["iid", "cartpole"],
+                    help="iid = S-iid synthetic log (headline); cartpole = CartPole dynamics + device box encoder (config C2)")
     ap.add_argument("--n-states", type=int, default=162)
     ap.add_argument("--n-actions", type=int, default=2)
     ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
@@ -86,7 +88,14 @@ def main():
 
     N, R = a.transitions, a.rollouts
     # this rank's shard of the log: shard g is generated from seed 20221107 + g (episode-disjoint by construction)
-    e = synth.synth_iid(N, a.n_states, a.n_actions, seed=20221107 + rank)
+    if a.workload == "cartpole":
+        from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+        e = synth.cartpole_log(N, seed=20221107 + rank)
+        enc = CartpoleBoxEncoder()
+        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+        a.n_states, a.n_actions = 162, 2
+    else:
+        e = synth.synth_iid(N, a.n_states, a.n_actions, seed=20221107 + rank)
     pi = synth.dirichlet_policy(a.n_states, a.n_actions)
     t0 = e["steps"] == 0
     table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=dev)
@@ -163,8 +172,8 @@ def main():
             "value": value, "unit": "simulated steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
-                                   f"evalMC_psrs to exhaustion, gamma={a.gamma}", "transitions_per_gpu": N, "rollouts": R,
+            "config": {"workload": (f"CartPole-dynamics log, uniform logger, device box encoder (C2), {N} transitions" if a.workload == "cartpole" else f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
+                                   f"evalMC_psrs to exhaustion, gamma={a.gamma}"), "transitions_per_gpu": N, "rollouts": R,
                        "shuffle": a.shuffle, "rollout_tile": tile, "p_log": "f32", "sharding": f"log sharded by episode over {world} GPU(s), "
                        "all seeds on every shard, RCCL all-reduce of per-seed (sum G, n episodes)"},
             "candidates_per_s": cand_pass * a.steps / elapsed, "acceptance": steps_pass / max(cand_pass, 1.0),
