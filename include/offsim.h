@@ -168,6 +168,27 @@ int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, i
                    double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
                    const offsim_evalmc_out *out, void *stream);
 
+/* Learner-in-the-loop drivers qlearn_psrs / expSARSA_psrs (offsim4rl/evaluators/psrs.py:119-239) for a behaviour
+ * policy that does not depend on Q (uniform: epsilon = 1, or a fixed tabular pi): evalMC's loop plus, after every
+ * accepted step (S, A, R, S'):
+ *   OFFSIM_TD_QLEARN   Q[S,A] += alpha * (R + gamma * max_a Q[S',a]            - Q[S,A])    (psrs.py:165-168)
+ *   OFFSIM_TD_EXPSARSA Q[S,A] += alpha * (R + gamma * sum_a Q[S',a] pi[S',a]   - Q[S,A])    (psrs.py:223)
+ * q [R,n_slots,nA] f64 is read as Q_init and written back; td_err [R,td_cap] (optional) gets the TD errors in step
+ * order.  pi [n_slots,nA] f64.  Outputs as offsim_eval_mc. */
+#define OFFSIM_TD_NONE 0
+#define OFFSIM_TD_QLEARN 1
+#define OFFSIM_TD_EXPSARSA 2
+typedef struct offsim_td {
+    int32_t mode;
+    double alpha;
+    double *q;
+    double *td_err;
+    int64_t td_cap;
+} offsim_td;
+int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi, int32_t reject_mode, double gamma,
+                   const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
+                   const offsim_td *td, void *stream);
+
 /* Fast path of evalMC_psrs for a fixed tabular policy (the headline scan).
  * offsim_compile_policy folds psrs.py:53-57 for policy pi [n_slots,nA] f64 into one 64-bit key per grouped row:
  *   key = T << 11 | done << 10 | z_next_slot,  T = floor(2^53 * pi[z][a]/p_log[a]/max_a'(pi[z][a']/p_log[a'])),

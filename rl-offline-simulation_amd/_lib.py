@@ -38,6 +38,13 @@ class EvalMCOut(C.Structure):
                 ("trace_cap", _i64), ("dbg", _vp)]
 
 
+class TD(C.Structure):
+    """struct offsim_td"""
+    _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64)]
+
+
+TD_QLEARN, TD_EXPSARSA = 1, 2
+
 # name -> (restype, argtypes): exactly the entry points include/offsim.h declares
 SIGNATURES = {
     "offsim_last_error": (C.c_char_p, []),
@@ -53,6 +60,8 @@ SIGNATURES = {
     "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), _vp]),
+    "offsim_eval_td": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_double, _vp, _i64, _i64,
+                                 C.POINTER(EvalMCOut), C.POINTER(TD), _vp]),
     "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),

@@ -563,17 +563,20 @@ __global__ void __launch_bounds__(256) k_step_batch(offsim_table t, offsim_rollo
 }
 
 // ---- eval_mc: the whole evalMC_psrs loop (psrs.py:241-271) on device, cursors in LDS ----
-template <typename PL, typename PROB>
+// TD = true adds the tabular learner of qlearn_psrs / expSARSA_psrs (psrs.py:119-239) to the loop: the rollout's
+// Q[n_slots,nA] lives in LDS and is updated after every accepted step, in step order.
+template <typename PL, typename PROB, bool TD>
 __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollouts ro, const PROB *__restrict__ pi,
                                                  int reject_mode, double gamma, const double *__restrict__ gamma_pow,
-                                                 int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out) {
+                                                 int64_t n_gamma_pow, int64_t max_episodes, offsim_evalmc_out out, offsim_td td) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int waves = blockDim.x / WAVE;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);  // uniform -> SGPR
     const int n_slots = t.n_slots, nA = t.nA;
-    // LDS carve: [jump tables][pi][seg_off][cursors per wave]
+    // LDS carve: [jump tables][Q per wave (TD only)][pi][seg_off][cursors per wave]
     Jump *tables = (Jump *)lds_raw;
-    PROB *pi_lds = (PROB *)(tables + waves * (WAVE + 1));
+    double *q_lds = (double *)(tables + waves * (WAVE + 1)) + (TD ? (size_t)wave * n_slots * nA : 0);
+    PROB *pi_lds = (PROB *)((double *)(tables + waves * (WAVE + 1)) + (TD ? (size_t)waves * n_slots * nA : 0));
     uint32_t *seg_lds = (uint32_t *)(pi_lds + (size_t)n_slots * nA);
     uint32_t *cur_lds = seg_lds + (n_slots + 1) + (size_t)wave * n_slots;
     for (int i = threadIdx.x; i < n_slots * nA; i += blockDim.x) pi_lds[i] = pi[i];
@@ -583,6 +586,8 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     if (r >= ro.R) return;
     uint32_t *cur_glb = ro.cursor + (int64_t)r * n_slots;
     for (int s = lane; s < n_slots; s += WAVE) cur_lds[s] = cur_glb[s];
+    if (TD)
+        for (int i = lane; i < n_slots * nA; i += WAVE) q_lds[i] = td.q[(int64_t)r * n_slots * nA + i];
 
     WaveRng rng;
     U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
@@ -626,6 +631,24 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
                 if (out.trace_row && steps < out.trace_cap) out.trace_row[(int64_t)r * out.trace_cap + steps] = t.orig_idx[s.g];
                 if (out.trace_pop && steps < out.trace_cap) out.trace_pop[(int64_t)r * out.trace_cap + steps] = s.popped;
             }
+            if (TD) {  // psrs.py:165-168 (Q-learning) / :223 (expected SARSA); every lane computes the same update
+                const int A = t.a[s.g];
+                const double q_sa = q_lds[slot * nA + A];
+                const double *qn = q_lds + (size_t)s.z_next * nA;
+                double nxt;
+                if (td.mode == OFFSIM_TD_QLEARN) {
+                    nxt = qn[0];
+                    for (int k = 1; k < nA; k++) nxt = qn[k] > nxt ? qn[k] : nxt;
+                } else {  // Q[S_] @ pi[S_]: left-to-right here; NumPy hands it to BLAS, so parity is to rounding only
+                    const PROB *pn = pi_lds + (size_t)s.z_next * nA;
+                    nxt = 0.0;
+                    for (int k = 0; k < nA; k++) nxt = nxt + qn[k] * (double)pn[k];
+                }
+                const double td_err = s.r + gamma * nxt - q_sa;
+                if (lane == 0 && td.td_err && steps < td.td_cap) td.td_err[(int64_t)r * td.td_cap + steps] = td_err;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                q_lds[slot * nA + A] = q_sa + td.alpha * td_err;
+            }
             G = G + gp * s.r;  // :262 (no FMA contraction: built with -ffp-contract=off)
             tt++;
             steps++;
@@ -639,11 +662,17 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
             if (lane == 0 && out.ep_g && ep < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep] = G;
             sum_g += G;
             ep++;
+        } else if (lane == 0 && out.ep_g && ep < out.ep_cap) {
+            // return of the episode cut short by exhaustion: evalMC_psrs drops it (:266), qlearn_psrs / expSARSA_psrs
+            // append it (psrs.py:177, :232); stored past the n_ep completed ones
+            out.ep_g[(int64_t)r * out.ep_cap + ep] = G;
         }
     }
     // write back the env state so that a later call continues where this one stopped
     __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int s = lane; s < n_slots; s += WAVE) cur_glb[s] = cur_lds[s];
+    if (TD)
+        for (int i = lane; i < n_slots * nA; i += WAVE) td.q[(int64_t)r * n_slots * nA + i] = q_lds[i];
     if (lane == 0) {
         ro.init_cursor[r] = ic;
         ro.cur_slot[r] = slot;
@@ -661,9 +690,9 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     }
 }
 
-static size_t evalmc_lds_bytes(int waves, int n_slots, int nA, size_t prob_bytes) {
-    return (size_t)waves * (WAVE + 1) * sizeof(Jump) + (size_t)n_slots * nA * prob_bytes + (size_t)(n_slots + 1) * 4 +
-           (size_t)waves * n_slots * 4;
+static size_t evalmc_lds_bytes(int waves, int n_slots, int nA, size_t prob_bytes, bool td = false) {
+    return (size_t)waves * (WAVE + 1) * sizeof(Jump) + (td ? (size_t)waves * n_slots * nA * 8 : 0) + (size_t)n_slots * nA * prob_bytes +
+           (size_t)(n_slots + 1) * 4 + (size_t)waves * n_slots * 4;
 }
 
 static int check_table(const offsim_table *t) {
@@ -726,15 +755,49 @@ extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const 
 #define LAUNCH_MC(PL, PROB)                                                                                          \
     do {                                                                                                             \
         if (lds > 64 * 1024)                                                                                         \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, PROB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_eval_mc<PL, PROB>), grid, block, lds, st, *t, *ro, (const PROB *)pi, reject_mode, gamma, \
-                           gamma_pow, n_gamma_pow, max_episodes, *out);                                              \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, PROB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_eval_mc<PL, PROB, false>), grid, block, lds, st, *t, *ro, (const PROB *)pi, reject_mode, gamma, \
+                           gamma_pow, n_gamma_pow, max_episodes, *out, offsim_td{});                                 \
     } while (0)
     if (prob_mode == OFFSIM_PROB_F32) LAUNCH_MC(float, float);
     else if (t->plog_dtype == OFFSIM_F32) LAUNCH_MC(float, double);
     else if (t->plog_dtype == OFFSIM_F64) LAUNCH_MC(double, double);
     else LAUNCH_MC(__half, double);
 #undef LAUNCH_MC
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with a state-independent behaviour policy: evalMC's loop plus the
+// tabular TD update, all R rollouts in one launch (generic 64-candidate step; f64 probabilities).
+extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi, int32_t reject_mode, double gamma,
+                              const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
+                              const offsim_td *td, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !pi || !out || !td) return fail(OFFSIM_EINVAL, "eval_td: bad argument%s");
+    if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
+        return fail(OFFSIM_EINVAL, "eval_td: required output is NULL%s");
+    if ((td->mode != OFFSIM_TD_QLEARN && td->mode != OFFSIM_TD_EXPSARSA) || !td->q) return fail(OFFSIM_EINVAL, "eval_td: bad td mode or NULL q%s");
+    if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_td: gamma_pow is NULL%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int waves = 4;
+    while (waves > 1 && evalmc_lds_bytes(waves, t->n_slots, t->nA, 8, true) > 64 * 1024) waves >>= 1;
+    size_t lds = evalmc_lds_bytes(waves, t->n_slots, t->nA, 8, true);
+    if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "eval_td: Q table, cursors and policy exceed 160 KiB of LDS%s");
+    dim3 grid((ro->R + waves - 1) / waves), block(waves * WAVE);
+#define LAUNCH_TD(PL)                                                                                                   \
+    do {                                                                                                                \
+        if (lds > 64 * 1024)                                                                                            \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_eval_mc<PL, double, true>), grid, block, lds, st, *t, *ro, pi, reject_mode, gamma, gamma_pow, \
+                           n_gamma_pow, max_episodes, *out, *td);                                                       \
+    } while (0)
+    if (t->plog_dtype == OFFSIM_F32) LAUNCH_TD(float);
+    else if (t->plog_dtype == OFFSIM_F64) LAUNCH_TD(double);
+    else LAUNCH_TD(__half);
+#undef LAUNCH_TD
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }

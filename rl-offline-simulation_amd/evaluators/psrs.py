@@ -145,6 +145,36 @@ class BatchedPSRS:
             o["_keepalive"] = (pi_d, gp)
         return o
 
+    # -- qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with a Q-independent behaviour policy, all rollouts in one launch --
+    def eval_td(self, pi_slots, gamma, mode, alpha, q_slots=None, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096):
+        """mode: _lib.TD_QLEARN | _lib.TD_EXPSARSA.  q_slots [R,n_slots,nA] f64 (Q_init; zeros if None) is updated in place
+        and returned as out["q"]; out["td_err"] [R,trace_cap] holds the TD errors in step order."""
+        t, dev, R = self.table, self.table.device, self.R
+        pi_d = torch.as_tensor(np.ascontiguousarray(pi_slots), dtype=torch.float64).to(dev).reshape(t.n_slots, t.nA).contiguous()
+        if n_episodes is None:
+            n_episodes = 1 << 62
+        q = torch.zeros((R, t.n_slots, t.nA), dtype=torch.float64, device=dev) if q_slots is None else \
+            torch.as_tensor(q_slots, dtype=torch.float64).to(dev).reshape(R, t.n_slots, t.nA).contiguous().clone()
+        o = {k: torch.empty(R, dtype=dt, device=dev) for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64), ("steps", torch.int64),
+                                                                   ("cand", torch.int64), ("n_len", torch.int64), ("status", torch.int32))}
+        if ep_cap:
+            o["ep_g"] = torch.zeros((R, ep_cap), dtype=torch.float64, device=dev)
+            o["ep_len"] = torch.zeros((R, ep_cap + 1), dtype=torch.int32, device=dev)
+        if trace_cap:
+            o["trace_row"] = torch.full((R, trace_cap), -1, dtype=torch.int32, device=dev)
+            o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
+            o["td_err"] = torch.zeros((R, trace_cap), dtype=torch.float64, device=dev)
+        gp = _gamma_pow(gamma, n_gamma_pow, dev)
+        oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
+                         n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")), ep_len=L.ptr(o.get("ep_len")),
+                         ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")), trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
+        tdc = L.TD(mode=mode, alpha=float(alpha), q=L.ptr(q), td_err=L.ptr(o.get("td_err")), td_cap=trace_cap)
+        L.check(L.load().offsim_eval_td(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), self.reject_mode, float(gamma), L.ptr(gp),
+                                        gp.numel(), int(n_episodes), C.byref(oc), C.byref(tdc), L.stream_ptr()))
+        o["q"] = q
+        o["_keepalive"] = (pi_d, gp)
+        return o
+
     def compile_policy(self, pi_d):
         """offsim_compile_policy: one 64-bit key per grouped row for the tabular policy pi_d [n_slots,nA] f64 (device)."""
         t = self.table
@@ -391,3 +421,127 @@ def evalMC_psrs(env, n_episodes, pi, gamma):
             Gs.append(G)
             episode += 1
     return np.array(Gs), np.array(lengths)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Learner-in-the-loop drivers (psrs.py:119-239)
+# ---------------------------------------------------------------------------------------------------
+def _q_to_slots(table, Q):
+    """Rows of a [nS,nA] table in slot order (NumPy indexing for z = -1), zeros where Q has no row."""
+    out = np.nan_to_num(table.policy_slots(np.asarray(Q, dtype=np.float64)), nan=0.0)
+    return out
+
+
+def _slots_to_q(table, q_slots, Q):
+    Q = np.array(Q, dtype=np.float64, copy=True)
+    for s in range(table.n_slots):
+        z = s + table.z_base
+        if -Q.shape[0] <= z < Q.shape[0]:
+            Q[z] = q_slots[s]
+    return Q
+
+
+def _fixed_behaviour(behavior_policy, nA, epsilon):
+    """The behaviour distribution if it does not depend on Q (e.g. epsilon = 1 or a uniform policy), else None."""
+    g = np.random.default_rng(0)
+    outs = [np.asarray(behavior_policy(q, dict(epsilon=epsilon)))[0] for q in (np.zeros((1, nA)), g.standard_normal((1, nA)), -g.random((1, nA)))]
+    return outs[0] if all(np.array_equal(outs[0], o) for o in outs[1:]) else None
+
+
+def _td_device(env, n_episodes, p_rows, gamma, alpha, mode, Q_init):
+    t = env.table
+    nS, nA = env.nS, env.nA
+    Q0 = np.zeros((nS, nA)) if Q_init is None else np.asarray(Q_init).copy().astype(float)
+    n_ep = int(min(n_episodes, t.N0 + 1))
+    o = env._env.eval_td(t.policy_slots(p_rows), gamma, mode, alpha, q_slots=_q_to_slots(t, Q0)[None], n_episodes=n_ep,
+                         ep_cap=n_ep + 1, trace_cap=t.N + 1)
+    status = int(o["status"].cpu()[0])
+    if status == L.ST_KEYERROR:
+        raise KeyError(int(env._env.state.cur_slot.cpu()[0]) + t.z_base)
+    ne, steps = int(o["n_ep"].cpu()[0]), int(o["steps"].cpu()[0])
+    n_g = ne + (1 if status == L.ST_EXHAUSTED else 0)  # the cut-short episode's return is appended too (psrs.py:177, :232)
+    Q = _slots_to_q(t, o["q"].cpu().numpy()[0], Q0)
+    rows = o["trace_row"].cpu().numpy()[0, :steps]
+    return Q, o["ep_g"].cpu().numpy()[0, :n_g].copy(), o["td_err"].cpu().numpy()[0, :steps].copy(), rows, Q0
+
+
+def _memory(env, rows, p_of_state):
+    return [(env._obs[r], env._a_of(r), env._r[r], env._next_obs[r], bool(env._done[r]), p_of_state(int(env._z[r])),
+             {"z": int(env._z[r]), "a": env._a_of(r), "p": env._p_of(r)}) for r in rows]
+
+
+def qlearn_psrs(env, n_episodes, behavior_policy, gamma, alpha=0.1, epsilon=1.0, Q_init=None, save_Q=0):
+    """psrs.py:119-185.  With a Q-independent behaviour policy (epsilon = 1, uniform, ...) on a device-backed PSRS the whole
+    loop -- PSRS steps and Q-learning updates -- is one kernel launch; otherwise the reference's host loop drives env.step."""
+    fixed = None
+    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not callable(epsilon) and not save_Q:
+        fixed = _fixed_behaviour(behavior_policy, env.nA, epsilon)
+    if fixed is not None:
+        t = env.table
+        p_rows = np.tile(np.asarray(fixed, dtype=np.float64), (max(env.nS, t.z_base + t.n_slots), 1))
+        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, p_rows, gamma, alpha, L.TD_QLEARN, Q_init)
+        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "TD_errors": td, "memory": _memory(env, rows, lambda z: fixed)}
+    epsilon_func = epsilon if callable(epsilon) else (lambda episode: epsilon)
+    alpha_func = alpha if callable(alpha) else (lambda episode: alpha)
+    Q = np.zeros((env.nS, env.nA)) if Q_init is None else Q_init.copy().astype(float)
+    Gs, Qs, TD_errors, memory_buffer = [], [Q.copy()], [], []
+    episode, terminate = 0, False
+    while episode < n_episodes and not terminate:
+        G, t = 0, 0
+        S = env.reset(seed=episode)
+        if S is None:
+            break
+        done = False
+        while not done:
+            p = behavior_policy(Q[[S], :], dict(epsilon=epsilon_func(episode)))[0]
+            S_, R, done, info = env.step(p)
+            if S_ is None:
+                terminate = True
+                break
+            A = info["a"]
+            memory_buffer.append((S, A, R, S_, done, p, info))
+            TD_errors.append(R + gamma * Q[S_].max() - Q[S, A])
+            Q[S, A] = Q[S, A] + alpha_func(episode) * (R + gamma * Q[S_].max() - Q[S, A])
+            S = S_
+            G = G + (gamma ** t) * R
+            t = t + 1
+            if save_Q:
+                Qs.append(Q.copy())
+        Gs.append(G)
+        episode += 1
+    return Q, {"Gs": np.array(Gs), "Qs": np.array(Qs), "TD_errors": np.array(TD_errors), "memory": memory_buffer}
+
+
+def expSARSA_psrs(env, n_episodes, pi, gamma, alpha=0.1, Q_init=None, save_Q=0):
+    """psrs.py:187-239: expected SARSA under a fixed target/behaviour policy pi; one launch on a device-backed PSRS."""
+    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not save_Q and \
+            isinstance(pi, np.ndarray) and pi.ndim == 2:
+        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, pi, gamma, alpha, L.TD_EXPSARSA, Q_init)
+        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "memory": _memory(env, rows, lambda z: pi[z])}
+    alpha_func = alpha if callable(alpha) else (lambda episode: alpha)
+    Q = np.zeros((env.nS, env.nA)) if Q_init is None else Q_init.copy().astype(float)
+    Gs, Qs, memory_buffer = [], [Q.copy()], []
+    episode, terminate = 0, False
+    while episode < n_episodes and not terminate:
+        G, t = 0, 0
+        S = env.reset(seed=episode)
+        if S is None:
+            break
+        done = False
+        while not done:
+            p = pi[S]
+            S_, R, done, info = env.step(p)
+            if S_ is None:
+                terminate = True
+                break
+            A = info["a"]
+            memory_buffer.append((S, A, R, S_, done, p, info))
+            Q[S, A] = Q[S, A] + alpha_func(episode) * (R + gamma * (Q[S_] @ pi[S_]) - Q[S, A])
+            S = S_
+            G = G + (gamma ** t) * R
+            t = t + 1
+            if save_Q:
+                Qs.append(Q.copy())
+        Gs.append(G)
+        episode += 1
+    return Q, {"Gs": np.array(Gs), "Qs": np.array(Qs), "memory": memory_buffer}

@@ -268,6 +268,29 @@ def main():
         inp["r"] = inp["r"].astype(np.float64)
         psrs_fixture(nm, inp, [0, 1], pi=pi162, gamma=0.99, p_new_step=np.array([0.5, 0.5]))
 
+    # ---- 11. learner-in-the-loop drivers (psrs.py:119-239) with a Q-independent behaviour policy ----
+    ref_tab = _load("ref_tabular", os.path.join(REF, "offsim4rl/agents/tabular.py"))
+    for nm, inp, pi_t, gam in (("td_iid_2k", iid2k, pi25, 0.9), ("td_grid_300x15", grid_big, pi25, 0.95)):
+        out = {("in_" + k): v for k, v in inp.items()}
+        out["seeds"], out["pi"], out["gamma"], out["alpha"] = np.array([0, 3], np.int64), pi_t, np.float64(gam), np.float64(0.1)
+        h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+        g = np.random.default_rng(99)
+        Qi = g.standard_normal((h.env.nS, 5)) * 0.1
+        out["Q_init"] = Qi
+        for s in (0, 3):
+            h.env.reset_sampler(seed=s)
+            h.clear()
+            Q, info = ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.uniformly_random_policy, gam, alpha=0.1, epsilon=1.0, Q_init=Qi)
+            out[f"s{s}_ql_Q"], out[f"s{s}_ql_Gs"], out[f"s{s}_ql_td"] = Q, info["Gs"], info["TD_errors"]
+            out[f"s{s}_ql_rows"] = np.array([r for r in h.rows if r >= 0], np.int64)
+            h.env.reset_sampler(seed=s)
+            h.clear()
+            Q, info = ref_psrs.expSARSA_psrs(h.env, 10 ** 9, pi_t, gam, alpha=0.1)
+            out[f"s{s}_es_Q"], out[f"s{s}_es_Gs"] = Q, info["Gs"]
+            out[f"s{s}_es_rows"] = np.array([r for r in h.rows if r >= 0], np.int64)
+        np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
+        print(f"{nm:28s} N={len(inp['z']):6d}")
+
     # ---- encoders ----
     cp = synth.cartpole_log(4096, seed=11)
     obs = cp["observations"].copy()
