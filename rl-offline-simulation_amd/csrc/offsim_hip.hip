@@ -852,7 +852,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
     if (rounds == 1) LAUNCH_WIN(32, 1);
     else if (rounds == 2) LAUNCH_WIN(16, 2);
-    else if (rounds == 3) LAUNCH_WIN(12, 3);
+    else if (rounds == 3) LAUNCH_WIN(8, 3);
     else LAUNCH_WIN(8, 4);
 #undef LAUNCH_WIN
     LAUNCH_CHECK();

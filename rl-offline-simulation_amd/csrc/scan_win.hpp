@@ -255,14 +255,29 @@ __global__ void __launch_bounds__(256, 4)
     uint64_t dm1 = 0, dm2 = 0;
     uint32_t n1 = 0, n2 = 0, st1 = 0;
     uint32_t tt_chain = 0;               // accepted steps since the last episode end, as of the end of the last logged phase
+    // Refill pipeline clock: every 16 accepted steps the next of the three stages runs (A request indices, B gather
+    // digests, C land in LDS), so a request lands 32 steps after it was made -- HBM latency is ~20x shorter than a tick.
+    uint32_t ticks_done = 0, stage_idx = 0;
+    auto refill_tick = [&]() {
+        if (stage_idx == 0) stageA();
+        else if (stage_idx == 1) stageB();
+        else stageC();
+        stage_idx = stage_idx == 2 ? 0u : stage_idx + 1u;
+    };
     auto flush = [&]() {
         // ---- uses first: everything consumed here was requested at least one phase ago ----
-        {   // R3: in-order discounted-return accumulation (psrs.py:262-269)
+        {   // R3: in-order discounted-return accumulation (psrs.py:262-269).  The sums must be sequential (bit-exact Gs),
+            // so the inner loop is just two v_readlane and one v_add_f64 per step; episode ends (about one per phase)
+            // are handled between runs of steps instead of being tested at every step.
             const double prod = gp2 * rv2;  // product first, then the running sum in step order
-            for (uint32_t i = 0; i < n2; i++) {
-                G = G + readlane_f64(prod, (int)i);
-                len_acc++;
-                if ((dm2 >> i) & 1ull) {
+            uint32_t i = 0;
+            uint64_t dm = dm2;
+            while (i < n2) {
+                const uint32_t e = dm ? (uint32_t)__ffsll((unsigned long long)dm) - 1u : n2;  // next episode end (index) or none
+                const uint32_t run_end = e < n2 ? e + 1u : n2;
+                len_acc += run_end - i;
+                for (; i < run_end; i++) G = G + readlane_f64(prod, (int)i);
+                if (e < n2) {
                     if (lane == 0) {
                         if (out.ep_g && (int64_t)ep_acc < out.ep_cap) out.ep_g[(int64_t)r * out.ep_cap + ep_acc] = G;
                         if (out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[(int64_t)r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
@@ -272,10 +287,10 @@ __global__ void __launch_bounds__(256, 4)
                     n_len++;
                     G = 0.0;
                     len_acc = 0;
+                    dm &= dm - 1ull;  // clear that done bit
                 }
             }
         }
-        stageC();
         // ---- then the new requests ----
         {   // R2
             double rv = 0.0;
@@ -292,8 +307,6 @@ __global__ void __launch_bounds__(256, 4)
             dm2 = dm1;
             n2 = n1;
         }
-        stageB();
-        stageA();
         {   // R1
             uint32_t g = 0;
             double gp = 0.0;
@@ -317,6 +330,7 @@ __global__ void __launch_bounds__(256, 4)
         }
         n_flush++;
     };
+
 
     // ---- the chain ----
     // Written as a straight-line fast loop (accept from the window) that leaves through ONE rarely-taken branch per
@@ -380,8 +394,8 @@ __global__ void __launch_bounds__(256, 4)
             slot = (int)(acc_dig & 1023u);
             kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
             m = meta[slot];                            // and the next state
-            // one scalar test for the three rare events: episode end | 64 steps logged | fewer than 64 draws left
-            if (__builtin_expect((((acc_dig >> 10) & 1u) | (nph >> 6) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
+            // one scalar test for the rare events: episode end | a multiple of 16 steps logged | fewer than 64 draws left
+            if (__builtin_expect((((acc_dig >> 10) & 1u) | ((((nph & 15u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
                 ev = EV_MISC;
                 break;
             }
@@ -456,7 +470,14 @@ __global__ void __launch_bounds__(256, 4)
         }
         // ---- common tail of every event: draws, phase boundary, episode end, refreshed prefetch ----
         while (gen < c + 64) gen_block();
-        if (nph == OFFSIM_PH) flush();
+        while (ticks_done < (nph >> 4)) {
+            refill_tick();
+            ticks_done++;
+        }
+        if (nph == OFFSIM_PH) {
+            flush();
+            ticks_done = 0;
+        }
         if (dn) {
             ep++;
             need_reset = true;
