@@ -227,59 +227,97 @@ __global__ void k_iota_rows(uint32_t *__restrict__ out, int64_t n_cols, int64_t 
 
 // Fisher-Yates chains: one per (state, rollout), each restarting default_rng(seed) (psrs.py:29-30), plus one per
 // rollout for the init queue (psrs.py:22-23).  A chain is a strictly sequential walk of random 4-byte swaps over its
-// own segment, so the kernel is bound by random-sector HBM traffic and by how many swaps are in flight:
+// own segment; with ~660 k chains in flight the kernel is bound by random-sector HBM traffic, so the job is to move
+// as few sectors as possible:
 //  - lanes of a wavefront take the SAME state of consecutive rollouts: equal trip counts, no divergence;
-//  - every lane interleaves CH independent chains (rollouts r, r + n_perm/CH, ...): CH swaps in flight per lane, and
-//    the whole job fits the chip's resident lanes in one round instead of a round and a ragged tail.
-template <int CH>
+//  - the descending side x[i] is processed in 64-byte blocks held in registers (one 16-word load, 16 swap steps, one
+//    16-word store): without this the line of x[i] is evicted between two visits of its lane (the chip holds 0.5 M
+//    chains but only 32 MiB of L2) and refetched, ~50 B per swap of pure waste (rocprofv3 FETCH_SIZE);
+//  - the random side x[j] is one 64-B sector read and one written back per swap: that part is inherent.
+struct ShuffleBlock {
+    uint32_t v[16];
+};
+__device__ __forceinline__ uint32_t blk_get(const ShuffleBlock &b, uint32_t k) {
+    uint32_t r = b.v[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) r = (k == (uint32_t)i) ? b.v[i] : r;
+    return r;
+}
+__device__ __forceinline__ void blk_set(ShuffleBlock &b, uint32_t k, uint32_t val) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) b.v[i] = (k == (uint32_t)i) ? val : b.v[i];
+}
+
 __global__ void k_shuffle_queues(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0,
-                                 const uint64_t *__restrict__ seeds, int32_t n_perm, int32_t per_lane_stride,
-                                 uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm) {
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_threads = (int64_t)(n_slots + 1) * per_lane_stride;
-    if (tid >= n_threads) return;
-    const int32_t s = (int32_t)(tid / per_lane_stride);
-    const int32_t r0 = (int32_t)(tid - (int64_t)s * per_lane_stride);
+                                 const uint64_t *__restrict__ seeds, int32_t n_perm, uint32_t *__restrict__ perm,
+                                 uint32_t *__restrict__ init_perm) {
+    const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_chains = (int64_t)(n_slots + 1) * n_perm;
+    if (chain >= n_chains) return;
+    const int32_t s = (int32_t)(chain / n_perm);
+    const int32_t r = (int32_t)(chain - (int64_t)s * n_perm);
+    uint32_t *x;
     uint32_t n;
-    int64_t row_stride;
-    uint32_t *x0;
     if (s < n_slots) {
         const uint32_t b = seg_off[s];
         n = seg_off[s + 1] - b;
-        x0 = perm + b;
-        row_stride = N;
+        x = perm + (int64_t)r * N + b;
     } else {  // the init queue
         n = (uint32_t)N0;
-        x0 = init_perm;
-        row_stride = N0;
+        x = init_perm + (int64_t)r * N0;
     }
     if (n < 2) return;
-    PcgSeq g[CH];
-    uint32_t *x[CH];
-    bool on[CH];
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-        const int32_t r = r0 + k * per_lane_stride;
-        on[k] = r < n_perm;
-        x[k] = x0 + (int64_t)(on[k] ? r : r0) * row_stride;
-        g[k].init(pcg_seed(seeds[on[k] ? r : r0]));
+    PcgSeq g;
+    g.init(pcg_seed(seeds[r]));
+    // 64-byte alignment of the blocks is by ADDRESS, so that one block is exactly one sector
+    const uint32_t mis = (uint32_t)(((uintptr_t)x >> 2) & 15u);  // words by which x[0] is past a 64-B boundary
+    uint32_t i = n - 1;
+    // head: single steps down to the first index that is the top word of a sector ((i + mis) % 16 == 15) with the
+    // whole sector inside the chain's remaining range (i >= 16, so that its bottom index is >= 1)
+    while (i >= 1 && !((((i + mis) & 15u) == 15u) && i >= 16u)) {
+        const uint32_t j = g.interval32(i);
+        const uint32_t xi = x[i], xj = x[j];
+        x[i] = xj;
+        x[j] = xi;
+        i--;
     }
-    for (uint32_t i = n - 1; i >= 1; i--) {
-        uint32_t j[CH], xi[CH], xj[CH];
+    // body: whole aligned blocks while the block bottom stays >= 1
+    while (i >= 16u) {
+        const uint32_t base = i - 15u;
+        ShuffleBlock blk;
+        const uint4 *src = (const uint4 *)(x + base);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        blk.v[0] = q0.x; blk.v[1] = q0.y; blk.v[2] = q0.z; blk.v[3] = q0.w;
+        blk.v[4] = q1.x; blk.v[5] = q1.y; blk.v[6] = q1.z; blk.v[7] = q1.w;
+        blk.v[8] = q2.x; blk.v[9] = q2.y; blk.v[10] = q2.z; blk.v[11] = q2.w;
+        blk.v[12] = q3.x; blk.v[13] = q3.y; blk.v[14] = q3.z; blk.v[15] = q3.w;
 #pragma unroll
-        for (int k = 0; k < CH; k++) j[k] = g[k].interval32(i);
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            xi[k] = x[k][i];
-            xj[k] = x[k][j[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            if (on[k]) {
-                x[k][i] = xj[k];
-                x[k][j[k]] = xi[k];
+        for (int k = 15; k >= 0; k--) {
+            const uint32_t ii = base + (uint32_t)k;
+            const uint32_t j = g.interval32(ii);
+            if (j >= base) {  // the partner is inside the register block (p = 16/i): swap in registers
+                const uint32_t t = blk_get(blk, j - base);
+                blk_set(blk, j - base, blk.v[k]);
+                blk.v[k] = t;
+            } else {
+                const uint32_t xj = x[j];
+                x[j] = blk.v[k];
+                blk.v[k] = xj;
             }
         }
+        uint4 *dst = (uint4 *)(x + base);
+        dst[0] = make_uint4(blk.v[0], blk.v[1], blk.v[2], blk.v[3]);
+        dst[1] = make_uint4(blk.v[4], blk.v[5], blk.v[6], blk.v[7]);
+        dst[2] = make_uint4(blk.v[8], blk.v[9], blk.v[10], blk.v[11]);
+        dst[3] = make_uint4(blk.v[12], blk.v[13], blk.v[14], blk.v[15]);
+        i = base - 1u;
+    }
+    // tail: the last few positions
+    for (; i >= 1; i--) {
+        const uint32_t j = g.interval32(i);
+        const uint32_t xi = x[i], xj = x[j];
+        x[i] = xj;
+        x[j] = xi;
     }
 }
 
@@ -301,20 +339,9 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
         hipLaunchKernelGGL(k_iota_rows, dim3(nb), dim3(256), 0, st, init_perm_out, t->N0, total);
         LAUNCH_CHECK();
     }
-    // chains per lane: measured at 10 M x 4096 (663 k chains), 2 interleaved chains per lane are 8 % SLOWER than 1
-    // (2.76 s vs 2.54 s): the kernel is bound by random-sector traffic (~115 B fetched + 64 B written per swap), not
-    // by swaps in flight.  The 2-chain instantiation is kept for small jobs that cannot fill the chip otherwise.
     const int64_t n_chains = (int64_t)(t->n_slots + 1) * n_perm;
-    const int ch = (n_chains < 65536 && n_perm >= 2) ? 2 : 1;
-    const int32_t per_lane_stride = (n_perm + ch - 1) / ch;
-    const int64_t n_threads = (int64_t)(t->n_slots + 1) * per_lane_stride;
-    dim3 grid((unsigned)((n_threads + 63) / 64)), block(64);
-    if (ch == 2)
-        hipLaunchKernelGGL(k_shuffle_queues<2>, grid, block, 0, st, t->seg_off, t->n_slots, t->N, t->N0, seeds, n_perm, per_lane_stride,
-                           perm_out, init_perm_out);
-    else
-        hipLaunchKernelGGL(k_shuffle_queues<1>, grid, block, 0, st, t->seg_off, t->n_slots, t->N, t->N0, seeds, n_perm, per_lane_stride,
-                           perm_out, init_perm_out);
+    hipLaunchKernelGGL(k_shuffle_queues, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
+                       n_perm, perm_out, init_perm_out);
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }
