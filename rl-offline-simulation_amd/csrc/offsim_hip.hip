@@ -868,7 +868,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     const int rounds = (t->n_slots + 63) / 64;
 #define LAUNCH_WIN(W, ROUNDS)                                                                                         \
     do {                                                                                                              \
-        size_t lds = (((size_t)(t->n_slots + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * ((size_t)t->n_slots * (W) * 4 + OFFSIM_RING * 4 + (size_t)t->n_slots * 8);                                \
+        size_t lds = (((size_t)(t->n_slots + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * ((size_t)t->n_slots * (W) * 4 + OFFSIM_RING * 4 + (size_t)t->n_slots * 16);                                \
         if (trace)                                                                                                    \
             hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \
@@ -878,7 +878,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     } while (0)
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
     if (rounds == 1) LAUNCH_WIN(32, 1);
-    else if (rounds == 2) LAUNCH_WIN(16, 2);
+    else if (rounds == 2) LAUNCH_WIN(8, 2);
     else if (rounds == 3) LAUNCH_WIN(8, 3);
     else LAUNCH_WIN(8, 4);
 #undef LAUNCH_WIN

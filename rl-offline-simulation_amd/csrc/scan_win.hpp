@@ -99,17 +99,19 @@ template <int W, int ROUNDS, bool TRACE>
 __global__ void __launch_bounds__(256, 4)
     k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
                   const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out) {
-    constexpr int D = W / 2;
+    constexpr int D = W > 8 ? 8 : 4;  // entries one request may bring (a visit consumes ~2-4 candidates; bigger requests cost more than they save)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int waves = blockDim.x / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;  // wave id is uniform: keep it scalar
     const int n_slots = t.n_slots;
     uint32_t *seg = (uint32_t *)lds_raw;
     const uint32_t seg_bytes = ((uint32_t)(n_slots + 1) * 4 + 15u) & ~15u;
-    const uint32_t win_bytes = (uint32_t)n_slots * W * 4, wave_bytes = win_bytes + OFFSIM_RING * 4 + (uint32_t)n_slots * 8;
+    const uint32_t win_bytes = (uint32_t)n_slots * W * 4, wave_bytes = win_bytes + OFFSIM_RING * 4 + (uint32_t)n_slots * 16;
     uint32_t *win = (uint32_t *)(lds_raw + seg_bytes + (size_t)wave * wave_bytes);
     uint32_t *ring = (uint32_t *)((unsigned char *)win + win_bytes);
-    uint2 *meta = (uint2 *)(ring + OFFSIM_RING);  // .x = cur (candidates popped), .y = landed (window valid up to)
+    uint2 *meta = (uint2 *)(ring + OFFSIM_RING);     // .x = cur (candidates popped), .y = landed (window valid up to)
+    uint32_t *fillq = (uint32_t *)(meta + n_slots);  // queue position up to which entries have been requested
+    uint32_t *claim = fillq + n_slots;               // refill ownership: which lane requests for a state this tick
     for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg[i] = t.seg_off[i];
     __syncthreads();
     const int r = blockIdx.x * waves + wave;
@@ -123,82 +125,35 @@ __global__ void __launch_bounds__(256, 4)
     const uint32_t n_gamma_pow = (uint32_t)(n_gamma_pow64 > 0x7fffffffll ? 0x7fffffffll : n_gamma_pow64);
     const uint32_t max_episodes = (uint32_t)(max_episodes64 > 0xffffffffll ? 0xffffffffll : max_episodes64);
 
-    // ---- refill pipeline registers: lane l of round q owns state q*64+l ----
-    uint32_t fill[ROUNDS];
-    uint32_t idxA[ROUNDS][D], posA[ROUNDS], cntA[ROUNDS];
-    uint32_t digB[ROUNDS][D], posB[ROUNDS], cntB[ROUNDS];
+    // ---- priming: every state's window is filled once, synchronously (lane = state) ----
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
-        int s = q * 64 + lane;
-        uint32_t c0 = s < n_slots ? cur_glb[s] : 0u;
-        if (s < n_slots) meta[s] = make_uint2(c0, c0);
-        fill[q] = c0;
-        posA[q] = cntA[q] = posB[q] = cntB[q] = 0;
+        const int s = q * 64 + lane;
+        if (s < n_slots) {
+            const uint32_t c0 = cur_glb[s], beg_s = seg[s], len_s = seg[s + 1] - beg_s;
+            const uint32_t left = len_s - c0, want = left < (uint32_t)W ? left : (uint32_t)W;
 #pragma unroll
-        for (int e2 = 0; e2 < D; e2++) idxA[q][e2] = digB[q][e2] = 0;
+            for (int e = 0; e < W; e++) {
+                if ((uint32_t)e < want) {
+                    const uint32_t p = beg_s + c0 + e;
+                    const uint32_t g = perm_row ? perm_row[p] : p;
+                    win[(uint32_t)s * W + (c0 + e) % W] = keys32[2 * (size_t)g + 1];
+                }
+            }
+            meta[s] = make_uint2(c0, c0 + want);
+            fillq[s] = c0 + want;
+        }
     }
-    auto stageC = [&]() {  // land the digests gathered one phase ago
+
+    // ---- refill pipeline, demand driven: the lane that logged a step also tops up the window of the state that step
+    // left.  Every 32 accepted steps one pass runs all three stages for different lane groups: the lanes of two ticks
+    // ago land their digests in LDS (C), the lanes of the previous tick gather digests through the indices that have
+    // arrived (B), the lanes of this tick request indices (A).  A request lands 2 ticks later; HBM latency is ~10x
+    // shorter than a tick, so no stage ever waits.
+    uint32_t rq_state = 0, rq_slot = 0, rq_pos = 0, rq_cnt = 0;
+    uint32_t idxA[D], digB[D];
 #pragma unroll
-        for (int q = 0; q < ROUNDS; q++) {
-            const int s = q * 64 + lane;
-            if (cntB[q]) {  // (implies s < n_slots)
-                const uint2 m = meta[s];
-                const uint32_t wbase = (uint32_t)s * W;
-#pragma unroll
-                for (int e = 0; e < D; e++) {
-                    uint32_t pos = posB[q] + e;
-                    if ((uint32_t)e < cntB[q] && pos >= m.x) win[wbase + pos % W] = digB[q][e];
-                }
-                const uint32_t end = posB[q] + cntB[q];
-                if (posB[q] <= m.y && end > m.y) meta[s].y = end;
-                cntB[q] = 0;
-            }
-        }
-    };
-    auto stageB = [&]() {  // permutation indices have arrived: gather the digests (high dword of each key)
-#pragma unroll
-        for (int q = 0; q < ROUNDS; q++) {
-#pragma unroll
-            for (int e = 0; e < D; e++)
-                if ((uint32_t)e < cntA[q]) digB[q][e] = keys32[2 * (size_t)idxA[q][e] + 1];
-            posB[q] = posA[q];
-            cntB[q] = cntA[q];
-            cntA[q] = 0;
-        }
-    };
-    auto stageA = [&]() {  // request the next entries of every state's queue
-#pragma unroll
-        for (int q = 0; q < ROUNDS; q++) {
-            const int s = q * 64 + lane;
-            uint32_t want = 0;
-            if (s < n_slots) {
-                const uint32_t cur_s = meta[s].x, beg_s = seg[s], len_s = seg[s + 1] - beg_s;
-                if (fill[q] < cur_s) fill[q] = cur_s;
-                const uint32_t have = fill[q] - cur_s;
-                const uint32_t room = have < (uint32_t)W ? (uint32_t)W - have : 0u;
-                const uint32_t left = len_s - fill[q];
-                want = room < (uint32_t)D ? room : (uint32_t)D;
-                want = want < left ? want : left;
-#pragma unroll
-                for (int e = 0; e < D; e++) {
-                    if ((uint32_t)e < want) {
-                        uint32_t p = beg_s + fill[q] + e;
-                        idxA[q][e] = perm_row ? perm_row[p] : p;
-                    }
-                }
-            }
-            posA[q] = fill[q];
-            cntA[q] = want;
-            fill[q] += want;
-        }
-    };
-    // synchronous priming: two full A-B-C rounds fill every window
-    stageA();
-    stageB();
-    stageC();
-    stageA();
-    stageB();
-    stageC();
+    for (int e = 0; e < D; e++) idxA[e] = digB[e] = 0;
 
     // ---- rejection stream: ring of the top 21 bits of the next draws ----
     U128 lane_state;
@@ -241,7 +196,7 @@ __global__ void __launch_bounds__(256, 4)
     double sum_g = 0.0, G = 0.0;
     int status = OFFSIM_ST_OK;
     // per-phase log: lane i remembers where the phase's i-th accepted step came from
-    uint32_t pos_log = 0, slot_log = 0, pop_log = 0;
+    uint32_t pos_log = 0, pop_log = 0;
     uint64_t done_mask = 0;
     uint32_t nph = 0, pop_acc = 0;
     const bool r64 = t.r_dtype == OFFSIM_F64;
@@ -255,14 +210,54 @@ __global__ void __launch_bounds__(256, 4)
     uint64_t dm1 = 0, dm2 = 0;
     uint32_t n1 = 0, n2 = 0, st1 = 0;
     uint32_t tt_chain = 0;               // accepted steps since the last episode end, as of the end of the last logged phase
-    // Refill pipeline clock: every 16 accepted steps the next of the three stages runs (A request indices, B gather
-    // digests, C land in LDS), so a request lands 32 steps after it was made -- HBM latency is ~20x shorter than a tick.
-    uint32_t ticks_done = 0, stage_idx = 0;
-    auto refill_tick = [&]() {
-        if (stage_idx == 0) stageA();
-        else if (stage_idx == 1) stageB();
-        else stageC();
-        stage_idx = stage_idx == 2 ? 0u : stage_idx + 1u;
+    uint32_t ticks_done = 0;
+    uint32_t slot_log = 0;  // (declared here: the refill pass reads the states the logged steps left)
+    auto refill_tick = [&](uint32_t lo, uint32_t hi) {
+        if (rq_state == 2) {  // C: land
+            const uint2 mm = meta[rq_slot];
+            const uint32_t wbase = rq_slot * W;
+#pragma unroll
+            for (int e = 0; e < D; e++) {
+                const uint32_t pos = rq_pos + e;
+                if ((uint32_t)e < rq_cnt && pos >= mm.x) win[wbase + pos % W] = digB[e];
+            }
+            const uint32_t end = rq_pos + rq_cnt;
+            if (rq_pos <= mm.y && end > mm.y) meta[rq_slot].y = end;
+            rq_state = 0;
+        }
+        if (rq_state == 1) {  // B: gather the digests (high dword of each key)
+#pragma unroll
+            for (int e = 0; e < D; e++)
+                if ((uint32_t)e < rq_cnt) digB[e] = keys32[2 * (size_t)idxA[e] + 1];
+            rq_state = 2;
+        }
+        const bool in_tick = (uint32_t)lane >= lo && (uint32_t)lane < hi;  // A: one request per state visited in this tick
+        if (in_tick) claim[slot_log] = (uint32_t)lane;
+        if (in_tick && claim[slot_log] == (uint32_t)lane) {
+            const uint32_t s_ = slot_log;
+            const uint32_t cur_s = meta[s_].x, beg_s = seg[s_], len_s = seg[s_ + 1] - beg_s;
+            uint32_t f = fillq[s_];
+            f = f < cur_s ? cur_s : f;
+            const uint32_t have = f - cur_s;
+            const uint32_t room = have < (uint32_t)W ? (uint32_t)W - have : 0u;
+            const uint32_t left = len_s - f;
+            uint32_t want = room < left ? room : left;
+            want = want < (uint32_t)D ? want : (uint32_t)D;
+            if (want) {
+#pragma unroll
+                for (int e = 0; e < D; e++) {
+                    if ((uint32_t)e < want) {
+                        const uint32_t p = beg_s + f + e;
+                        idxA[e] = perm_row ? perm_row[p] : p;
+                    }
+                }
+                rq_slot = s_;
+                rq_pos = f;
+                rq_cnt = want;
+                rq_state = 1;
+                fillq[s_] = f + want;
+            }
+        }
     };
     auto flush = [&]() {
         // ---- uses first: everything consumed here was requested at least one phase ago ----
@@ -394,8 +389,8 @@ __global__ void __launch_bounds__(256, 4)
             slot = (int)(acc_dig & 1023u);
             kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
             m = meta[slot];                            // and the next state
-            // one scalar test for the rare events: episode end | a multiple of 16 steps logged | fewer than 64 draws left
-            if (__builtin_expect((((acc_dig >> 10) & 1u) | ((((nph & 15u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
+            // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
+            if (__builtin_expect((((acc_dig >> 10) & 1u) | ((((nph & 31u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
                 ev = EV_MISC;
                 break;
             }
@@ -451,6 +446,7 @@ __global__ void __launch_bounds__(256, 4)
             if ((uint32_t)lane >= d && (uint32_t)lane < keep_end) win[(uint32_t)slot * W + (cur_z + lane) % W] = (uint32_t)(key >> 32);
             const uint32_t new_land = cur_z + keep_end;
             meta[slot] = make_uint2(cur_z + d, land_z < new_land ? new_land : land_z);
+            if (fillq[slot] < new_land) fillq[slot] = new_land;
             c += d;
             if (TRACE) pop_acc += d;
             if (f >= 0) {
@@ -470,8 +466,8 @@ __global__ void __launch_bounds__(256, 4)
         }
         // ---- common tail of every event: draws, phase boundary, episode end, refreshed prefetch ----
         while (gen < c + 64) gen_block();
-        while (ticks_done < (nph >> 4)) {
-            refill_tick();
+        while (ticks_done < (nph >> 5)) {
+            refill_tick(ticks_done << 5, (ticks_done << 5) + 32u);
             ticks_done++;
         }
         if (nph == OFFSIM_PH) {
