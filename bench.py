@@ -66,6 +66,26 @@ def cpu_baseline(e, pi, gamma, n_sample, budget_s):
                       f"same synthetic log, {el:.1f} s of oracle/psrs_oracle.c on one host core"}
 
 
+def pmc_traffic(a):
+    """Bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/, collected by tools/profile_bench.sh; PMC cannot be read from inside the run).  FETCH_SIZE/WRITE_SIZE
+    in KB; 4-byte random-sector gathers are counted 1:1 on this GPU (tools/calib_fetch.py), and the counters sit on
+    the fabric side of L2, i.e. they include Infinity-Cache hits: an upper bound of the HBM bytes."""
+    default = (a.workload == "iid" and a.transitions == 10_000_000 and a.rollouts == 4096 and a.n_states == 162 and
+               a.n_actions == 2 and a.shuffle == "per_rollout")
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_bench_10Mx4096", "summary.json")
+    if not default or not os.path.exists(path):
+        return None, None
+    try:
+        s = json.load(open(path))
+        calls = [int(r["Calls"]) for r in s["kernel_stats"] if "k_eval_mc_win" in r["Name"]][0]
+        kb = sum(v.get("FETCH_SIZE", 0.0) for k, v in s["pmc_fetch"].items() if "k_eval_mc_win" in k)
+        kb += sum(v.get("WRITE_SIZE", 0.0) for k, v in s["pmc_write"].items() if "k_eval_mc_win" in k)
+        return kb * 1024.0 / calls, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_rocprof_bench_10Mx4096), fabric-side: includes Infinity-Cache hits"
+    except Exception:
+        return None, None
+
+
 def main():
     a = parse()
     import torch
@@ -167,6 +187,7 @@ def main():
         achieved = alg_bytes_pass * a.steps / t_scan / 1e9
         value = steps_pass * a.steps / elapsed
         vest = (est[:, 0] / est[:, 1]).cpu().numpy()
+        traffic, traffic_src = pmc_traffic(a)
         out = {
             "metric": "simulated steps/sec (node), 10M logged transitions x 4096 rollouts",
             "value": value, "unit": "simulated steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -182,7 +203,7 @@ def main():
             "scan_only_steps_per_s": my_steps * a.steps / t_scan, "reset_sampler_s_per_pass": t_reset / a.steps,
             "scan_s_per_pass": t_scan / a.steps,
             "roofline": {"bound": "hbm", "kernel": "k_eval_mc_win (offsim_eval_mc_keys)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_pass / max(n_scan / a.steps, 1),
                          "bytes_per_candidate": b_c, "bytes_per_step": b_s, "launches": n_scan,
                          "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3},

@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256, 4)
             meta[slot].x = m.x + d;
             c += d;
             if (TRACE) pop_acc += d;
-        } else if (ev == EV_DRY || ev == EV_TIE) {  // 64 candidates straight from HBM with full keys
+        } else if (ev == EV_DRY || ev == EV_TIE) {  // candidates straight from HBM with full keys
             if (ev == EV_DRY) n_dry++;
             else n_tie++;
             const uint32_t cur_z = __builtin_amdgcn_readfirstlane(m.x), land_z = __builtin_amdgcn_readfirstlane(m.y);
@@ -416,7 +416,10 @@ __global__ void __launch_bounds__(256, 4)
                 status = OFFSIM_ST_EXHAUSTED;
                 break;
             }
-            const uint32_t nv = rem < 64u ? rem : 64u;
+            // 16 candidates per direct read: enough that "none accepted" is a 1e-5 event, and 4x fewer random sectors
+            // than a full wavefront of gathers (each 4..8-byte gather moves a 64-byte sector)
+            constexpr uint32_t DIRECT = W > 16 ? (uint32_t)W + 16u : 16u;
+            const uint32_t nv = rem < DIRECT ? rem : DIRECT;
             const bool valid = (uint32_t)lane < nv;
             const uint32_t p = beg_z + cur_z + (valid ? lane : 0);
             const uint32_t g = perm_row ? perm_row[p] : p;
