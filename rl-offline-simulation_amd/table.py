@@ -70,7 +70,7 @@ class TransitionTable:
             p_log = p_log.to(_TORCH_OF[np.dtype(plog_dtype)])
         if p_log.dtype not in _TAG_OF:
             p_log = p_log.to(torch.float64)
-        p_log = p_log.reshape(N, -1).contiguous()
+        p_log = (p_log.reshape(N, -1) if N else p_log.reshape(0, p_log.shape[-1] if p_log.dim() > 1 else 1)).contiguous()
         self.nA = int(p_log.shape[1])
         r = _dev(r, device)
         if r.dtype not in (torch.float32, torch.float64):

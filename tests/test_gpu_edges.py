@@ -1,0 +1,121 @@
+"""Edge cases the reference's behaviour defines: empty and ragged inputs, odd rollout counts, many states (generic
+kernel), large seeds, episode caps -- every one against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    return torch.device("cuda", 0)
+
+
+def _compare(e, pi, gamma, seeds, gpu, n_episodes=None, fast=None):
+    from oracle import oracle as O
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds)
+    N = len(e["z"])
+    o = env.eval_mc(table.policy_slots(pi), gamma, n_episodes=n_episodes, ep_cap=table.N0 + 1, trace_cap=N + 1, fast=fast)
+    torch.cuda.synchronize()
+    ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    for i, s in enumerate(seeds):
+        ora.reset_sampler(s)
+        try:
+            ref = ora.evalmc(10 ** 9 if n_episodes is None else n_episodes, pi, gamma, trace_cap=N + 1)
+        except KeyError:
+            assert int(o["status"][i]) == 3
+            continue
+        n = ref["steps"]
+        assert int(o["steps"][i]) == n and int(o["cand"][i]) == ref["candidates"]
+        assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])
+        ne = int(o["n_ep"][i])
+        assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+        assert np.array_equal(o["ep_len"][i, : int(o["n_len"][i])].cpu().numpy(), ref["lengths"])
+    return table, o
+
+
+def test_empty_dataset(gpu):
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS, PSRS
+    z = np.zeros(0, np.int64)
+    table = TransitionTable(z, z, np.zeros(0), z, np.zeros(0, bool), np.zeros((0, 3)), np.zeros(0, bool), device=gpu)
+    assert table.N == 0 and table.N0 == 0
+    env = BatchedPSRS(table, 3)
+    env.reset_sampler([1, 2, 3])
+    o = env.eval_mc(np.full((table.n_slots, 3), 1 / 3), 0.9)
+    torch.cuda.synchronize()
+    assert o["status"].cpu().tolist() == [2, 2, 2] and o["steps"].cpu().tolist() == [0, 0, 0]
+    single = PSRS.from_arrays(z, z, np.zeros(0), z, np.zeros(0, bool), np.zeros((0, 3)), np.zeros(0, bool), nS=1, nA=3)
+    assert single.reset() is None  # psrs.py:33-35
+
+
+@pytest.mark.parametrize("R", [1, 3, 5, 67])
+def test_odd_rollout_counts(R, gpu):
+    from rl_offline_simulation_amd import synth
+    e = synth.synth_iid(3000, 12, 3, seed=R)
+    _compare(e, synth.dirichlet_policy(12, 3), 0.9, list(range(100, 100 + R)), gpu)
+
+
+def test_ragged_segments_and_single_rows(gpu):
+    """States with 0, 1 and 2 rows next to a dominant state; self-loops; every row terminal; no terminal at all."""
+    from rl_offline_simulation_amd import synth
+    g = np.random.default_rng(0)
+    N = 4000
+    e = synth.synth_iid(N, 40, 2, seed=4)
+    z = np.where(g.random(N) < 0.7, 5, e["z"])          # one dominant state
+    zn = np.where(g.random(N) < 0.5, z, e["z_next"])     # half of the transitions are self-loops
+    z[:3] = [37, 38, 38]                                  # 1-row and 2-row queues; state 39 never occurs as a from-state
+    e = dict(e, z=z, z_next=zn, observations=z, next_observations=zn)
+    pi = synth.dirichlet_policy(40, 2)
+    _compare(e, pi, 0.99, [0, 1, 2, 3], gpu)
+    _compare(dict(e, terminals=np.ones(N, bool)), pi, 0.99, [0, 1], gpu)
+    _compare(dict(e, terminals=np.zeros(N, bool)), pi, 0.99, [0, 1], gpu)
+
+
+def test_many_states_take_the_generic_kernel(gpu):
+    from rl_offline_simulation_amd import synth, _lib
+    e = synth.synth_iid(30_000, 700, 3, seed=9)
+    table, o = _compare(e, synth.dirichlet_policy(700, 3), 0.95, [0, 1, 2], gpu)
+    assert table.n_slots > 256
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    env = BatchedPSRS(table, 1)
+    env.reset_sampler([0])
+    with pytest.raises(_lib.OffsimError):
+        env.eval_mc(table.policy_slots(synth.dirichlet_policy(700, 3)), 0.95, fast=True)
+
+
+def test_large_seeds_and_episode_caps(gpu):
+    from rl_offline_simulation_amd import synth
+    e = synth.synth_iid(5000, 25, 5, seed=6)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = [2 ** 32 - 1, 2 ** 32, 2 ** 40 + 5, 2 ** 63 + 11]
+    _compare(e, pi, 0.99, seeds, gpu)
+    for cap in (0, 1, 7):
+        for fast in (True, False):
+            _compare(e, pi, 0.99, [3, 4], gpu, n_episodes=cap, fast=fast)
+
+
+def test_shared_and_table_order_modes_agree_between_kernels(gpu):
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(20_000, 60, 4, seed=12)
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi = table.policy_slots(synth.dirichlet_policy(60, 4))
+    for mode in ("shared", "table_order"):
+        outs = []
+        for fast in (True, False):
+            env = BatchedPSRS(table, 6)
+            env.reset_sampler(list(range(6)), mode, shuffle_seed=77)
+            outs.append(env.eval_mc(pi, 0.9, trace_cap=20_001, fast=fast))
+        torch.cuda.synchronize()
+        for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status", "trace_row", "trace_pop"):
+            assert torch.equal(outs[0][k], outs[1][k]), (mode, k)
