@@ -93,6 +93,32 @@ class BatchedPSRS:
                                            L.ptr(self._row), L.ptr(self._status), L.ptr(self._popped), L.stream_ptr()))
         return self._row, self._status, self._popped
 
+    def step_single(self, p_new, advance=True, reject_mode=None):
+        """R = 1 convenience for the drop-in classes: one H2D copy, one launch, one D2H copy through pinned buffers.
+        Returns host ints (row, status, popped)."""
+        t = self.table
+        p_new = np.asarray(p_new)
+        mode = _prob_mode(t, p_new.dtype)
+        key = (mode, t.nA)
+        if getattr(self, "_single_key", None) != key:
+            dt = torch.float32 if mode == L.PROB_F32 else torch.float64
+            self._p_host = torch.empty((1, t.nA), dtype=dt).pin_memory()
+            self._p_dev = torch.empty((1, t.nA), dtype=dt, device=t.device)
+            self._o_dev = torch.empty(3, dtype=torch.int32, device=t.device)
+            self._o_host = torch.empty(3, dtype=torch.int32).pin_memory()
+            self._single_key = key
+        self._p_host.copy_(torch.from_numpy(np.ascontiguousarray(p_new.reshape(1, -1))))
+        self._p_dev.copy_(self._p_host, non_blocking=True)
+        rm = self.reject_mode if reject_mode is None else reject_mode
+        base = self._o_dev.data_ptr()
+        L.check(L.load().offsim_step_batch(C.byref(t.c), C.byref(self.state.c), L.ptr(self._p_dev), mode, rm, 1 if advance else 0,
+                                           base, base + 4, base + 8, L.stream_ptr()))
+        self._o_host.copy_(self._o_dev, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        row, status, popped = self._o_host.tolist()
+        self.last_row = row
+        return row, status, popped
+
     def set_state(self, slots, mask=None):
         s = slots.to(device=self.table.device, dtype=torch.int32).contiguous()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
@@ -289,12 +315,10 @@ class PSRS:
         p_new = np.asarray(p_new)
         z = self.z
         if self._reject_func is None:
-            row, status, popped = self._env.step(p_new.reshape(1, -1))
-            row, status = int(row.cpu()[0]), int(status.cpu()[0])
+            row, status, popped = self._env.step_single(p_new)
         else:  # Python-side _reject hook: pop candidates one at a time and ask the callable (psrs.py:48)
             while True:
-                row, status, _ = self._env.step(p_new.reshape(1, -1), advance=False, reject_mode=L.REJECT_NEVER)
-                row, status = int(row.cpu()[0]), int(status.cpu()[0])
+                row, status, _ = self._env.step_single(p_new, advance=False, reject_mode=L.REJECT_NEVER)
                 if status != L.ST_OK:
                     break
                 if not self._reject_func(p_new, self._p_of(row), self._a_of(row)):

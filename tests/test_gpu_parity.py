@@ -118,7 +118,7 @@ def test_golden_step_protocol(name, gpu):
                 if obs is None:
                     rows.append(-1)
                     break
-                rows.append(int(env._env._row.cpu()[0]))
+                rows.append(env._env.last_row)
                 if done:
                     obs = env.reset()
                     resets.append(-2 if obs is None else env.z)
