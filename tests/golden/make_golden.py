@@ -291,6 +291,60 @@ def main():
         np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
         print(f"{nm:28s} N={len(inp['z']):6d}")
 
+    # ---- 12. QueueEvaluator_impl (queue_evaluator.py:90-131): (z, a)-keyed queues, no rejection.  The module imports gym at
+    # the top, so only the class (numpy + itertools) is compiled from the reference file, unmodified, in memory.
+    import ast
+    import itertools
+    src = open(os.path.join(REF, "offsim4rl/evaluators/queue_evaluator.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "QueueEvaluator_impl"][0]
+    ns = {"np": np, "itertools": itertools}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "queue_evaluator.py", "exec"), ns)
+    QImpl = ns["QueueEvaluator_impl"]
+    for nm, inp in (("queue_grid_300x15", grid_big), ("queue_iid_2k", iid2k)):
+        N = len(inp["z"])
+        buf = [(int(inp["z"][i]), int(inp["a"][i]), float(inp["r"][i]), int(inp["z_next"][i]), bool(inp["done"][i]), None,
+                {"z": int(inp["z"][i]), "next_z": int(inp["z_next"][i]), "t": 0 if inp["t0"][i] else 1, "idx": i}) for i in range(N)]
+        out = {("in_" + k): v for k, v in inp.items()}
+        out["seeds"] = np.array([0, 4], np.int64)
+        for s in (0, 4):
+            env = QImpl(buf, nS=25, nA=5)
+            env.reset_sampler(seed=s)
+            keys = sorted(env.queues.keys())
+            out[f"s{s}_keys"] = np.array(keys, np.int64)
+            out[f"s{s}_off"] = np.cumsum([0] + [len(env.queues[k]) for k in keys]).astype(np.int64)
+            out[f"s{s}_queue"] = np.array([e_[8]["idx"] for k in keys for e_ in env.queues[k]], np.int64)
+            g = np.random.default_rng(1000 + s)
+            acts, rows, events = [], [], []
+            obs = env.reset()
+            for _ in range(4 * N):
+                if obs is None:
+                    break
+                a = int(g.integers(0, 5))
+                acts.append(a)
+                try:
+                    L0 = {k: len(v) for k, v in env.queues.items()}
+                    key = (env.z, a)
+                    head = env.queues[key][0][8]["idx"] if key in env.queues and env.queues[key] else -1
+                    o2, r2, d2, info = env.step(a)
+                except KeyError:
+                    rows.append(-3)
+                    events.append(3)
+                    obs = env.reset()
+                    continue
+                if o2 is None:
+                    rows.append(-1)
+                    events.append(1)
+                    obs = env.reset()
+                    continue
+                rows.append(head)
+                events.append(0)
+                obs = o2
+                if d2:
+                    obs = env.reset()
+            out[f"s{s}_actions"], out[f"s{s}_rows"], out[f"s{s}_events"] = np.array(acts, np.int64), np.array(rows, np.int64), np.array(events, np.int64)
+        np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
+        print(f"{nm:28s} N={N:6d}")
+
     # ---- encoders ----
     cp = synth.cartpole_log(4096, seed=11)
     obs = cp["observations"].copy()

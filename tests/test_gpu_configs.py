@@ -173,3 +173,68 @@ def test_td_host_loop_fallback_matches_device(gpu):
     Qh, info_h = qlearn_psrs(env, 10 ** 9, uniform, 0.9, alpha=lambda ep: 0.1)  # callable alpha forces the host loop
     assert np.array_equal(Qd, Qh) and np.array_equal(info_d["Gs"], info_h["Gs"])
     assert np.array_equal(info_d["TD_errors"], info_h["TD_errors"])
+
+
+@pytest.mark.parametrize("name", ["queue_grid_300x15", "queue_iid_2k"])
+def test_queue_evaluator_golden(name, gpu):
+    """QueueEvaluator (queue_evaluator.py:8-131): (z, a)-keyed queues, agent-chosen actions, no rejection.  Queue orders and
+    the served rows under a fixed action sequence must equal the reference's."""
+    from common import load
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces
+    from rl_offline_simulation_amd.evaluators import QueueEvaluator
+    d = load(name)
+    ds = OfflineDataset(spaces.Discrete(25), spaces.Discrete(5), ProbDistribution.Discrete, observations=d["in_z"], actions=d["in_a"],
+                        rewards=d["in_r"], next_observations=d["in_z_next"], terminals=d["in_done"],
+                        action_distributions=d["in_p_log"], steps=np.where(d["in_t0"], 0, 1))
+    env = QueueEvaluator(ds)
+    t = env._impl.table
+    for s in d["seeds"]:
+        s = int(s)
+        env.reset_sampler(s)
+        # queue orders: composite slots with a non-empty queue <-> the reference's sorted (z, a) keys
+        seg = t.seg_off.cpu().numpy().astype(np.int64)
+        lens = np.diff(seg)
+        comp = np.nonzero(lens)[0]
+        keys = np.stack([comp // 5 + env._impl.z_lo, comp % 5], 1)
+        assert np.array_equal(keys, d[f"s{s}_keys"])
+        q = t.order.cpu().numpy().astype(np.int64)[env._impl.env.state.perm[0].cpu().numpy().astype(np.int64)][: t.N]
+        assert np.array_equal(q, d[f"s{s}_queue"])
+        events = []
+        obs = env.reset()
+        for a in d[f"s{s}_actions"]:
+            assert obs is not None
+            try:
+                o2, r2, d2, info = env.step(int(a))
+            except KeyError:
+                events.append(3)
+                obs = env.reset()
+                continue
+            if o2 is None:
+                events.append(1)
+                obs = env.reset()
+                continue
+            assert info["a"] == int(a)
+            events.append(0)
+            obs = o2
+            if d2:
+                obs = env.reset()
+        assert events == d[f"s{s}_events"].tolist()
+    # served rows: replay once more recording the device's row ids
+    env.reset_sampler(int(d["seeds"][0]))
+    s = int(d["seeds"][0])
+    got = []
+    obs = env.reset()
+    for a in d[f"s{s}_actions"]:
+        row, status = env._impl.step([int(a)])
+        row, status = int(row.cpu()[0]), int(status.cpu()[0])
+        if status == 3:
+            got.append(-3)
+            env.reset()
+        elif status != 0:
+            got.append(-1)
+            env.reset()
+        else:
+            got.append(row)
+            if d["in_done"][row]:
+                env.reset()
+    assert got == d[f"s{s}_rows"].tolist()
