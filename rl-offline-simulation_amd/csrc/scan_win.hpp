@@ -331,7 +331,6 @@ __global__ void __launch_bounds__(256, 4)
     // Written as a straight-line fast loop (accept from the window) that leaves through ONE rarely-taken branch per
     // kind of event; a single wave pays ~10 cycles per dependent instruction and ~25 per taken branch, so the shape of
     // this loop, not memory, sets the kernel time.
-    enum { EV_DRY = 0, EV_TIE = 1, EV_ALLREJ = 2, EV_MISC = 3 };
     bool need_reset = true, dn = false;
     uint2 m = make_uint2(0u, 0u);
     uint32_t kt = 0;
@@ -351,9 +350,13 @@ __global__ void __launch_bounds__(256, 4)
             m = meta[slot];
             kt = ring[(c + lane) & (OFFSIM_RING - 1)];
         }
-        int ev;
-        for (;;) {  // fast loop: one iteration = one accepted step served from the LDS window
-            const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop leaves as "all rejected"
+        // fast loop: one iteration = one accepted step served from the LDS window.  Single exit (`go`), so that the
+        // back edge is one scalar branch; why it stopped is read from (ok, many) afterwards.
+        uint32_t last_dig = 0;
+        uint64_t many = 0;
+        bool ok = false, go = false;
+        do {
+            const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop stops as "all rejected"
             const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
             uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
             wi = wi >= (uint32_t)W ? wi - W : wi;
@@ -361,50 +364,55 @@ __global__ void __launch_bounds__(256, 4)
             uint32_t dig = win[(uint32_t)slot * W + wi];
             dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
             const uint32_t Tt = dig >> 11;
-            const uint64_t many = __ballot(kt <= Tt);
-            if (__builtin_expect(many == 0, 0)) {
-                ev = EV_ALLREJ;
-                break;
-            }
+            many = __ballot(kt <= Tt);
             const uint64_t macc = __ballot(kt < Tt);
-            const int f = __ffsll((unsigned long long)many) - 1;
-            if (__builtin_expect(!((macc >> f) & 1ull), 0)) {
-                ev = EV_TIE;  // top-21-bit tie (or a draw of exactly 0 on an empty lane): exact compare needed
-                break;
+            // f = first lane that is not a clear reject (s_ff1 gives -1 when there is none: the shift then reads bit 63 of
+            // macc, which is always 0 because lanes >= W carry an empty digest); ok = that lane is a clear accept
+            int f;
+            asm("s_ff1_i32_b64 %0, %1" : "=s"(f) : "s"(many));
+            ok = ((macc >> (f & 63)) & 1ull) != 0ull;
+            go = false;
+            if (__builtin_expect(ok, 1)) {
+                const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
+                const uint32_t v_pos = m.x + (uint32_t)f;
+                meta[slot].x = v_pos + 1u;
+                const bool mine = (uint32_t)lane == nph;
+                pos_log = mine ? v_pos : pos_log;
+                slot_log = mine ? (uint32_t)slot : slot_log;
+                c += (uint32_t)f + 1u;
+                if (TRACE) {
+                    pop_log = mine ? pop_acc + (uint32_t)f + 1u : pop_log;
+                    pop_acc = 0;
+                }
+                const uint32_t dn_bit = (acc_dig >> 10) & 1u;
+                done_mask |= (uint64_t)dn_bit << nph;
+                nph++;
+                slot = (int)(acc_dig & 1023u);
+                kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
+                m = meta[slot];                            // and the next state
+                last_dig = acc_dig;
+                // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
+                go = (dn_bit | ((((nph & 31u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) == 0u;
             }
-            const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
-            const uint32_t v_pos = m.x + (uint32_t)f;
-            meta[slot].x = v_pos + 1u;
-            const bool mine = (uint32_t)lane == nph;
-            pos_log = mine ? v_pos : pos_log;
-            slot_log = mine ? (uint32_t)slot : slot_log;
-            c += (uint32_t)f + 1u;
-            if (TRACE) {
-                pop_log = mine ? pop_acc + (uint32_t)f + 1u : pop_log;
-                pop_acc = 0;
-            }
-            dn = (acc_dig >> 10) & 1u;
-            done_mask |= (uint64_t)dn << nph;
-            nph++;
-            slot = (int)(acc_dig & 1023u);
-            kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
-            m = meta[slot];                            // and the next state
-            // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
-            if (__builtin_expect((((acc_dig >> 10) & 1u) | ((((nph & 31u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) != 0u, 0)) {
-                ev = EV_MISC;
-                break;
-            }
+        } while (__builtin_expect(go, 1));
+        if (ok) {
+            dn = (last_dig >> 10) & 1u;
+            goto ev_tail;
         }
-        if (ev == EV_ALLREJ && __builtin_amdgcn_readfirstlane(m.y - m.x) == 0u) ev = EV_DRY;
-        if (ev == EV_ALLREJ) {  // every window candidate rejected: consume them, look again
-            const uint32_t v_avail = m.y - m.x;
-            const uint32_t d = __builtin_amdgcn_readfirstlane(v_avail < (uint32_t)W ? v_avail : (uint32_t)W);
-            meta[slot].x = m.x + d;
-            c += d;
-            if (TRACE) pop_acc += d;
-        } else if (ev == EV_DRY || ev == EV_TIE) {  // candidates straight from HBM with full keys
-            if (ev == EV_DRY) n_dry++;
-            else n_tie++;
+        if (many == 0ull) {
+            if (__builtin_amdgcn_readfirstlane(m.y - m.x) != 0u) {  // every window candidate rejected: consume them, look again
+                const uint32_t v_avail = m.y - m.x;
+                const uint32_t d = __builtin_amdgcn_readfirstlane(v_avail < (uint32_t)W ? v_avail : (uint32_t)W);
+                meta[slot].x = m.x + d;
+                c += d;
+                if (TRACE) pop_acc += d;
+                goto ev_tail;
+            }
+            n_dry++;
+        } else {
+            n_tie++;  // top-21-bit tie (or a draw of exactly 0 on an empty lane): exact compare needed
+        }
+        {  // dry window or tie: candidates straight from HBM with full keys
             const uint32_t cur_z = __builtin_amdgcn_readfirstlane(m.x), land_z = __builtin_amdgcn_readfirstlane(m.y);
             const uint32_t beg_z = seg[slot], len_z = seg[slot + 1] - beg_z;
             if (len_z == 0) {  // KeyError (psrs.py:44)
@@ -467,6 +475,7 @@ __global__ void __launch_bounds__(256, 4)
                 slot = (int)(acc_dig & 1023u);
             }
         }
+    ev_tail:
         // ---- common tail of every event: draws, phase boundary, episode end, refreshed prefetch ----
         while (gen < c + 64) gen_block();
         while (ticks_done < (nph >> 5)) {
