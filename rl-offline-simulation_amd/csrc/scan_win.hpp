@@ -196,8 +196,7 @@ __global__ void __launch_bounds__(256, 4)
     double sum_g = 0.0, G = 0.0;
     int status = OFFSIM_ST_OK;
     // per-phase log: lane i remembers where the phase's i-th accepted step came from
-    uint32_t pos_log = 0, pop_log = 0;
-    uint64_t done_mask = 0;
+    uint32_t pos_log = 0, pop_log = 0, dig_log = 0;
     uint32_t nph = 0, pop_acc = 0;
     const bool r64 = t.r_dtype == OFFSIM_F64;
 
@@ -303,6 +302,7 @@ __global__ void __launch_bounds__(256, 4)
             n2 = n1;
         }
         {   // R1
+            const uint64_t done_mask = __ballot((uint32_t)lane < nph && ((dig_log >> 10) & 1u));  // episode ends of this phase
             uint32_t g = 0;
             double gp = 0.0;
             if ((uint32_t)lane < nph) {
@@ -321,7 +321,6 @@ __global__ void __launch_bounds__(256, 4)
             tt_chain = done_mask ? nph - 1u - (63u - (uint32_t)__clzll((long long)done_mask)) : tt_chain + nph;
             steps += nph;
             nph = 0;
-            done_mask = 0;
         }
         n_flush++;
     };
@@ -353,49 +352,63 @@ __global__ void __launch_bounds__(256, 4)
         // fast loop: one iteration = one accepted step served from the LDS window.  Single exit (`go`), so that the
         // back edge is one scalar branch; why it stopped is read from (ok, many) afterwards.
         uint32_t last_dig = 0;
-        uint64_t many = 0;
-        bool ok = false, go = false;
+        uint64_t many = 0, macc = 0;
+        uint32_t stop;  // 0 = keep going
+        // the current state also lives in a VGPR inside the loop: its address arithmetic then runs on the VALU instead
+        // of the one scalar ALU that the CU's 16 rollouts share (the loop was scalar-issue bound)
+        uint32_t vslot;
+        asm("v_mov_b32 %0, %1" : "=v"(vslot) : "s"(slot));
+        int vrel = lane - (int)nph;                       // lane - (steps logged this phase): the lane with 0 logs the next step
+        const uint32_t nph_in = nph;
+        int tick_b = (int)(31u - (nph & 31u));            // goes negative when a multiple of 32 steps has been logged
+        const int b_in = tick_b;
+        const uint32_t gen_m64 = gen - 64u;
         do {
             const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop stops as "all rejected"
             const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
             uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
             wi = wi >= (uint32_t)W ? wi - W : wi;
             wi = lane < W ? wi : 0u;
-            uint32_t dig = win[(uint32_t)slot * W + wi];
+            uint32_t dig = win[vslot * W + wi];
             dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
             const uint32_t Tt = dig >> 11;
             many = __ballot(kt <= Tt);
-            const uint64_t macc = __ballot(kt < Tt);
+            macc = __ballot(kt < Tt);
             // f = first lane that is not a clear reject (s_ff1 gives -1 when there is none: the shift then reads bit 63 of
             // macc, which is always 0 because lanes >= W carry an empty digest); ok = that lane is a clear accept
             int f;
             asm("s_ff1_i32_b64 %0, %1" : "=s"(f) : "s"(many));
-            ok = ((macc >> (f & 63)) & 1ull) != 0ull;
-            go = false;
-            if (__builtin_expect(ok, 1)) {
+            stop = 1u;
+            if (__builtin_expect(((macc >> (f & 63)) & 1ull) != 0ull, 1)) {
                 const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
                 const uint32_t v_pos = m.x + (uint32_t)f;
-                meta[slot].x = v_pos + 1u;
-                const bool mine = (uint32_t)lane == nph;
+                meta[vslot].x = v_pos + 1u;
+                const bool mine = vrel == 0;
+                vrel -= 1;
+                uint32_t vdig;
+                asm("v_mov_b32 %0, %1" : "=v"(vdig) : "s"(acc_dig));
                 pos_log = mine ? v_pos : pos_log;
-                slot_log = mine ? (uint32_t)slot : slot_log;
+                slot_log = mine ? vslot : slot_log;
+                dig_log = mine ? vdig : dig_log;          // its bit 10 is the episode-end flag of the step
                 c += (uint32_t)f + 1u;
                 if (TRACE) {
                     pop_log = mine ? pop_acc + (uint32_t)f + 1u : pop_log;
                     pop_acc = 0;
                 }
-                const uint32_t dn_bit = (acc_dig >> 10) & 1u;
-                done_mask |= (uint64_t)dn_bit << nph;
-                nph++;
-                slot = (int)(acc_dig & 1023u);
+                tick_b -= 1;
+                vslot = vdig & 1023u;
                 kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
-                m = meta[slot];                            // and the next state
+                m = meta[vslot];                           // and the next state
                 last_dig = acc_dig;
                 // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
-                go = (dn_bit | ((((nph & 31u) - 1u)) >> 31) | ((gen - c - 64u) >> 31)) == 0u;
+                stop = ((acc_dig >> 10) & 1u) | (((uint32_t)tick_b | (gen_m64 - c)) >> 31);
             }
-        } while (__builtin_expect(go, 1));
-        if (ok) {
+        } while (__builtin_expect(stop == 0u, 1));
+        slot = (int)__builtin_amdgcn_readfirstlane(vslot);
+        nph = nph_in + (uint32_t)(b_in - tick_b);
+        int f_last;
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(f_last) : "s"(many));
+        if (((macc >> (f_last & 63)) & 1ull) != 0ull) {  // the last look accepted: left for a rare event
             dn = (last_dig >> 10) & 1u;
             goto ev_tail;
         }
@@ -469,8 +482,8 @@ __global__ void __launch_bounds__(256, 4)
                     pop_log = mine ? pop_acc : pop_log;
                     pop_acc = 0;
                 }
+                dig_log = mine ? acc_dig : dig_log;
                 dn = (acc_dig >> 10) & 1u;
-                done_mask |= (uint64_t)dn << nph;
                 nph++;
                 slot = (int)(acc_dig & 1023u);
             }
