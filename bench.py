@@ -40,30 +40,51 @@ def parse():
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-transitions", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
 def cpu_baseline(e, pi, gamma, n_sample, budget_s):
-    """The oracle (C port of the reference loop, one thread) on a bounded sample of the same workload."""
+    """The oracle (C port of the reference loop) on a bounded sample of the same workload, on all host cores: rollouts
+    are independent, so each thread owns one oracle object and runs whole rollouts (ctypes releases the GIL)."""
+    import threading
     from oracle import oracle as O
     sl = slice(0, n_sample)
     t0 = e["steps"][sl] == 0
-    ora = O.OraclePSRS(e["z"][sl], e["actions"][sl], e["rewards"][sl], e["z_next"][sl], e["terminals"][sl],
-                       e["action_distributions"][sl], t0)
-    steps, n_roll = 0, 0
+    cols = (e["z"][sl], e["actions"][sl], e["rewards"][sl], e["z_next"][sl], e["terminals"][sl], e["action_distributions"][sl], t0)
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    O.lib()
+    steps = [0] * cores
+    rolls = [0] * cores
     t_start = time.perf_counter()
-    while True:
-        ora.reset_sampler(n_roll)
-        res = ora.evalmc(10 ** 9, pi, gamma)
-        steps += res["steps"]
-        n_roll += 1
-        el = time.perf_counter() - t_start
-        if el > budget_s or n_roll >= 4096:
-            break
-    return {"value": steps / el, "unit": "simulated steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_roll} rollouts (reset_sampler + evalMC to exhaustion) over the first {n_sample} transitions of the "
-                      f"same synthetic log, {el:.1f} s of oracle/psrs_oracle.c on one host core"}
+
+    def work(k):
+        ora = O.OraclePSRS(*cols)
+        seed = k
+        while True:
+            ora.reset_sampler(seed)
+            steps[k] += ora.evalmc(10 ** 9, pi, gamma)["steps"]
+            rolls[k] += 1
+            seed += cores
+            if time.perf_counter() - t_start > budget_s or seed >= 4096:
+                break
+
+    # one core first (the reference itself is single-threaded), then all of them
+    work(0)
+    el1 = time.perf_counter() - t_start
+    v1, r1 = steps[0] / el1, rolls[0]
+    steps[0] = rolls[0] = 0
+    t_start = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    el = time.perf_counter() - t_start
+    return {"value": sum(steps) / el, "unit": "simulated steps/s", "cores": cores, "kind": "port", "value_one_core": v1,
+            "sample": f"{sum(rolls)} rollouts (reset_sampler + evalMC to exhaustion) over the first {n_sample} transitions of the same "
+                      f"synthetic log, {el:.1f} s of oracle/psrs_oracle.c on {cores} host threads (one rollout per thread); "
+                      f"one thread alone: {r1} rollouts in {el1:.1f} s"}
 
 
 def pmc_traffic(a):
