@@ -99,6 +99,8 @@ template <int W, int ROUNDS, bool TRACE>
 __global__ void __launch_bounds__(256, 4)
     k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
                   const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out) {
+    constexpr uint32_t TICK = W > 16 ? 16u : 32u;  // accepted steps between refill passes (few busy states: refill sooner)
+    constexpr uint32_t TICK_LOG = W > 16 ? 4u : 5u;
     constexpr int D = W > 8 ? 8 : 4;  // entries one request may bring (a visit consumes ~2-4 candidates; bigger requests cost more than they save)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int waves = blockDim.x / 64;
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(256, 4)
         asm("v_mov_b32 %0, %1" : "=v"(vslot) : "s"(slot));
         int vrel = lane - (int)nph;                       // lane - (steps logged this phase): the lane with 0 logs the next step
         const uint32_t nph_in = nph;
-        int tick_b = (int)(31u - (nph & 31u));            // goes negative when a multiple of 32 steps has been logged
+        int tick_b = (int)((TICK - 1u) - (nph & (TICK - 1u)));  // goes negative when a multiple of TICK steps has been logged
         const int b_in = tick_b;
         const uint32_t gen_m64 = gen - 64u;
         do {
@@ -491,8 +493,8 @@ __global__ void __launch_bounds__(256, 4)
     ev_tail:
         // ---- common tail of every event: draws, phase boundary, episode end, refreshed prefetch ----
         while (gen < c + 64) gen_block();
-        while (ticks_done < (nph >> 5)) {
-            refill_tick(ticks_done << 5, (ticks_done << 5) + 32u);
+        while (ticks_done < (nph >> TICK_LOG)) {
+            refill_tick(ticks_done << TICK_LOG, (ticks_done << TICK_LOG) + TICK);
             ticks_done++;
         }
         if (nph == OFFSIM_PH) {
