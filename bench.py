@@ -58,19 +58,19 @@ def cpu_baseline(e, pi, gamma, n_sample, budget_s):
     rolls = [0] * cores
     t_start = time.perf_counter()
 
-    def work(k):
+    def work(k, stride=None):
         ora = O.OraclePSRS(*cols)
         seed = k
         while True:
             ora.reset_sampler(seed)
             steps[k] += ora.evalmc(10 ** 9, pi, gamma)["steps"]
             rolls[k] += 1
-            seed += cores
+            seed += cores if stride is None else stride
             if time.perf_counter() - t_start > budget_s or seed >= 4096:
                 break
 
     # one core first (the reference itself is single-threaded), then all of them
-    work(0)
+    work(0, stride=1)
     el1 = time.perf_counter() - t_start
     v1, r1 = steps[0] / el1, rolls[0]
     steps[0] = rolls[0] = 0
