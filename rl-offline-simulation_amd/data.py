@@ -64,3 +64,37 @@ class OfflineDataset:
 
     def __len__(self):
         return int(np.shape(self.experience["observations"])[0])
+
+    # ---- ingestion formats ----
+    # The reference stores datasets as HDF5: one gzip dataset per experience key, the spaces and the
+    # ProbDistribution pickled into group attributes (data.py:85-98, 120-146).  h5py is not part of this stack, so
+    # the native container here is .npz with the same keys; HDF5 files written by the reference load through
+    # load_hdf5 wherever h5py is importable.
+    def save_npz(self, path):
+        import pickle
+        meta = np.frombuffer(pickle.dumps((self.observation_space, self.action_space, self.action_dist_type)), dtype=np.uint8)
+        np.savez_compressed(path, __spaces__=meta, **{k: np.asarray(v) for k, v in self.experience.items()})
+
+    @classmethod
+    def load_npz(cls, path):
+        import pickle
+        with np.load(path, allow_pickle=False) as z:
+            obs_space, act_space, dist_type = pickle.loads(z["__spaces__"].tobytes())
+            return cls(obs_space, act_space, dist_type, **{k: z[k] for k in z.files if k != "__spaces__"})
+
+    @classmethod
+    def load_hdf5(cls, path, group_name=None):
+        """data.py:81-83 / HDF5Dataset (data.py:120-146): arrays are read into memory (the device table copies them anyway)."""
+        try:
+            import h5py
+        except ImportError as e:  # pragma: no cover - h5py is absent from the build image
+            raise ImportError("load_hdf5 needs h5py; convert with the reference's tools or use save_npz/load_npz") from e
+        import pickle
+        with h5py.File(path, "r") as fin:
+            group = fin.get(group_name, default=fin) if group_name else fin
+
+            def attr(name, default=None):
+                b = group.attrs.get(name, default=None)
+                return pickle.loads(b.tobytes()) if b is not None else default
+            return cls(attr("observation_space"), attr("action_space"), attr("action_dist_type", ProbDistribution.NoProbability),
+                       **{k: np.asarray(group[k]) for k in group})

@@ -151,3 +151,17 @@ def test_policy_slots_numpy_indexing():
     pi = np.arange(8.0).reshape(4, 2)
     out = TransitionTable.policy_slots(T, pi)
     assert np.array_equal(out[0], pi[-1]) and np.array_equal(out[1:], pi[:3])
+
+
+def test_dataset_npz_round_trip(tmp_path):
+    """The round trip the reference's tests/test_data.py pins for HDF5, on the .npz container used here."""
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces, synth
+    e = synth.cartpole_log(500, seed=2)
+    keys = ("observations", "actions", "rewards", "next_observations", "terminals", "steps", "episode_ids", "action_distributions")
+    ds = OfflineDataset(spaces.Box(-5, 5, (4,)), spaces.Discrete(2), ProbDistribution.Discrete, **{k: e[k] for k in keys})
+    path = str(tmp_path / "d.npz")
+    ds.save_npz(path)
+    back = OfflineDataset.load_npz(path)
+    assert back.action_space.n == 2 and back.observation_space.shape == (4,) and back.action_dist_type == ProbDistribution.Discrete
+    for k in keys:
+        assert np.array_equal(back.experience[k], e[k]) and back.experience[k].dtype == e[k].dtype
