@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--tile", type=int, default=4096, help="rollouts whose queue permutations are resident at once")
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="plumbing test: several ranks share GPU 0 (use with --dist-backend gloo)")
     ap.add_argument("--cpu-sample-transitions", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -121,10 +123,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the PSRS engine has no CPU fallback")
+    if a.all_ranks_on_device0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend)
     _lib.load()
 
     N, R = a.transitions, a.rollouts
