@@ -168,6 +168,16 @@ int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, i
                    double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
                    const offsim_evalmc_out *out, void *stream);
 
+/* PSRS_Exo.step (offsim4rl/evaluators/psrs.py:99-117): endogenous state s and exogenous state x have their own queue
+ * families; every candidate pops the head of both, the accept/reject test reads the s-row, the accepted s-row gives
+ * (r, s', done) and the accepted x-row gives x'.  ts / rs: table grouped by s and its rollout state (rng, cursors,
+ * permutations, cur_slot = s); tx / rx: table grouped by x (only z_next and orig_idx are read) and its cursors,
+ * permutations and cur_slot = x.  Build, shuffle and reset each with the ordinary entry points (same seeds).
+ * out_row_s / out_row_x: caller-buffer rows of the accepted s- and x-elements (-1 on None / KeyError). */
+int offsim_step_exo(const offsim_table *ts, const offsim_table *tx, offsim_rollouts *rs, offsim_rollouts *rx,
+                    const void *p_new, int32_t prob_mode, int32_t *out_row_s, int32_t *out_row_x, int32_t *out_status,
+                    uint32_t *out_popped, void *stream);
+
 /* Learner-in-the-loop drivers qlearn_psrs / expSARSA_psrs (offsim4rl/evaluators/psrs.py:119-239) for a behaviour
  * policy that does not depend on Q (uniform: epsilon = 1, or a fixed tabular pi): evalMC's loop plus, after every
  * accepted step (S, A, R, S'):

@@ -60,6 +60,8 @@ SIGNATURES = {
     "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), _vp]),
+    "offsim_step_exo": (C.c_int, [C.POINTER(Table), C.POINTER(Table), C.POINTER(Rollouts), C.POINTER(Rollouts), _vp, _i32,
+                                  _vp, _vp, _vp, _vp, _vp]),
     "offsim_eval_td": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), C.POINTER(TD), _vp]),
     "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),

@@ -795,6 +795,124 @@ extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const 
     return OFFSIM_OK;
 }
 
+// ---- PSRS_Exo.step (psrs.py:99-117): two queue families, endogenous state s and exogenous state x.  Every candidate
+// pops the head of BOTH s_queues[s] and x_queues[x]; the rejection test reads the s-row (a, p_log); the accepted
+// candidate's s-row gives (r, s', done) and its x-row gives x'.  Lane k tests candidate k of both queues with draw c+k.
+template <typename PL, typename PROB>
+__global__ void __launch_bounds__(256) k_step_exo(offsim_table ts, offsim_table tx, offsim_rollouts rs, offsim_rollouts rx,
+                                                  const PROB *__restrict__ p_new, int32_t *__restrict__ out_row_s,
+                                                  int32_t *__restrict__ out_row_x, int32_t *__restrict__ out_status,
+                                                  uint32_t *__restrict__ out_popped) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+    const int r = blockIdx.x * (blockDim.x / WAVE) + wave;
+    if (r >= rs.R) return;
+    const int ss = rs.cur_slot[r], xs = rx.cur_slot[r];
+    int status = OFFSIM_ST_OK;
+    uint32_t popped = 0;
+    int32_t row_s = -1, row_x = -1;
+    if (ss < 0 || xs < 0) status = OFFSIM_ST_INACTIVE;
+    else if (ss >= ts.n_slots || xs >= tx.n_slots) status = OFFSIM_ST_KEYERROR;
+    if (status == OFFSIM_ST_OK) {
+        const uint32_t beg_s = ts.seg_off[ss], len_s = ts.seg_off[ss + 1] - beg_s;
+        const uint32_t beg_x = tx.seg_off[xs], len_x = tx.seg_off[xs + 1] - beg_x;
+        if (len_s == 0 || len_x == 0) status = OFFSIM_ST_KEYERROR;  // self.s_queues[s] / self.x_queues[x] raise KeyError
+        else {
+            Jump *table = (Jump *)lds_raw + wave * (WAVE + 1);
+            WaveRng rng;
+            const U128 base = u128(rs.rng[4 * r + 0], rs.rng[4 * r + 1]);
+            const U128 inc = u128(rs.rng[4 * r + 2], rs.rng[4 * r + 3]);
+            wave_rng_init(rng, table, base, inc);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            uint32_t cur_s = rs.cursor[(int64_t)r * ts.n_slots + ss], cur_x = rx.cursor[(int64_t)r * tx.n_slots + xs];
+            const uint32_t *perm_s = rs.perm ? rs.perm + (int64_t)r * rs.perm_stride : nullptr;
+            const uint32_t *perm_x = rx.perm ? rx.perm + (int64_t)r * rx.perm_stride : nullptr;
+            const PL *plog = (const PL *)ts.p_log;
+            const PROB *pn = p_new + (int64_t)r * ts.nA;
+            uint64_t consumed = 0;
+            int32_t ns = -1, nx = -1;
+            for (;;) {
+                const uint32_t rem_s = len_s - cur_s, rem_x = len_x - cur_x;
+                const uint32_t rem = rem_s < rem_x ? rem_s : rem_x;
+                if (rem == 0) {  // psrs.py:104-107
+                    status = OFFSIM_ST_EXHAUSTED;
+                    break;
+                }
+                const uint32_t nv = rem < WAVE ? rem : WAVE;
+                const bool valid = (uint32_t)lane < nv;
+                uint32_t gs = beg_s + cur_s + (valid ? lane : 0), gx = beg_x + cur_x + (valid ? lane : 0);
+                if (perm_s) gs = perm_s[gs];
+                if (perm_x) gx = perm_x[gx];
+                const int a = ts.a[gs];
+                const uint64_t k53 = pcg_output(rng.lane_state) >> 11;
+                bool rej;
+                if constexpr (sizeof(PROB) == 4) rej = rejects_f32((const float *)plog, (int64_t)gs, a, (const float *)pn, ts.nA, k53);
+                else rej = rejects_f64<PL>(plog, (int64_t)gs, a, (const double *)pn, ts.nA, k53);
+                const uint64_t m = __ballot(valid && !rej);
+                const int f = m ? __ffsll((unsigned long long)m) - 1 : -1;
+                const uint32_t d = f < 0 ? nv : (uint32_t)f + 1;
+                cur_s += d;
+                cur_x += d;
+                popped += d;
+                consumed += d;
+                rng.lane_state = pcg_apply(rng.table[d], rng.lane_state);
+                if (f >= 0) {
+                    const int gsf = __builtin_amdgcn_readlane((int)gs, f), gxf = __builtin_amdgcn_readlane((int)gx, f);
+                    row_s = ts.orig_idx[gsf];
+                    row_x = tx.orig_idx[gxf];
+                    ns = ts.z_next[gsf];
+                    nx = tx.z_next[gxf];
+                    break;
+                }
+            }
+            if (lane == 0) {
+                rs.cursor[(int64_t)r * ts.n_slots + ss] = cur_s;
+                rx.cursor[(int64_t)r * tx.n_slots + xs] = cur_x;
+                if (consumed) {
+                    U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
+                    rs.rng[4 * r + 0] = nb.hi;
+                    rs.rng[4 * r + 1] = nb.lo;
+                }
+                if (status == OFFSIM_ST_OK) {  // psrs.py:116
+                    rs.cur_slot[r] = ns;
+                    rx.cur_slot[r] = nx;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (out_row_s) out_row_s[r] = status == OFFSIM_ST_OK ? row_s : -1;
+        if (out_row_x) out_row_x[r] = status == OFFSIM_ST_OK ? row_x : -1;
+        if (out_status) out_status[r] = status;
+        if (out_popped) out_popped[r] = popped;
+    }
+}
+
+extern "C" int offsim_step_exo(const offsim_table *ts, const offsim_table *tx, offsim_rollouts *rs, offsim_rollouts *rx,
+                               const void *p_new, int32_t prob_mode, int32_t *out_row_s, int32_t *out_row_x,
+                               int32_t *out_status, uint32_t *out_popped, void *stream) {
+    int rc = check_table(ts);
+    if (rc) return rc;
+    rc = check_table(tx);
+    if (rc) return rc;
+    if (!rs || !rx || rs->R != rx->R || rs->R < 0 || !p_new) return fail(OFFSIM_EINVAL, "step_exo: bad argument%s");
+    if (rs->R == 0) return OFFSIM_OK;
+    if (prob_mode == OFFSIM_PROB_F32 && ts->plog_dtype != OFFSIM_F32) return fail(OFFSIM_EINVAL, "step_exo: OFFSIM_PROB_F32 needs an f32 p_log%s");
+    hipStream_t st = (hipStream_t)stream;
+    const int waves = 4;
+    dim3 grid((rs->R + waves - 1) / waves), block(waves * WAVE);
+    size_t lds = (size_t)waves * (WAVE + 1) * sizeof(Jump);
+#define LAUNCH_EXO(PL, PROB) \
+    hipLaunchKernelGGL((k_step_exo<PL, PROB>), grid, block, lds, st, *ts, *tx, *rs, *rx, (const PROB *)p_new, out_row_s, out_row_x, out_status, out_popped)
+    if (prob_mode == OFFSIM_PROB_F32) LAUNCH_EXO(float, float);
+    else if (ts->plog_dtype == OFFSIM_F32) LAUNCH_EXO(float, double);
+    else if (ts->plog_dtype == OFFSIM_F64) LAUNCH_EXO(double, double);
+    else LAUNCH_EXO(__half, double);
+#undef LAUNCH_EXO
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 // qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with a state-independent behaviour policy: evalMC's loop plus the
 // tabular TD update, all R rollouts in one launch (generic 64-candidate step; f64 probabilities).
 extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi, int32_t reject_mode, double gamma,

@@ -2,3 +2,4 @@ from .psrs import PSRS, BatchedPSRS, evalMC_psrs, evalmc_rollouts, qlearn_psrs, 
 from .per_state_rejection import PerStateRejectionSampling  # noqa: F401
 from .trivial_baselines import FollowObservationOnly, FollowActionOnly, ServeRandomTransitions  # noqa: F401
 from .queue_evaluator import QueueEvaluator, BatchedQueueEvaluator  # noqa: F401
+from .psrs_exo import PSRS_Exo  # noqa: F401

@@ -345,6 +345,45 @@ def main():
         np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
         print(f"{nm:28s} N={N:6d}")
 
+    # ---- 13. PSRS_Exo (psrs.py:59-117): observations o = 4 s + x, endogenous s and exogenous x queued separately ----
+    gx = np.random.default_rng(321)
+    N = 2000
+    xs, xn = gx.integers(0, 4, N), gx.integers(0, 4, N)
+    split = lambda o: (o // 4, o % 4)
+    combine = lambda s, x: s * 4 + x
+    p_rows = [np.array(iid2k["p_log"][i]) for i in range(N)]
+    pid = {(p_rows[i].tobytes(), int(iid2k["a"][i]), float(iid2k["r"][i])): i for i in range(N)}  # PSRS_Exo deep-copies its buffer
+    assert len(pid) == N
+    buf = [(int(iid2k["z"][i]) * 4 + int(xs[i]), int(iid2k["a"][i]), float(iid2k["r"][i]), int(iid2k["z_next"][i]) * 4 + int(xn[i]),
+            bool(iid2k["done"][i]), p_rows[i], {"t": 0 if iid2k["t0"][i] else 1}) for i in range(N)]
+    out = dict(in_o=np.array([b[0] for b in buf], np.int64), in_a=iid2k["a"], in_r=iid2k["r"], in_o_next=np.array([b[3] for b in buf], np.int64),
+               in_done=iid2k["done"], in_p_log=iid2k["p_log"], in_t0=iid2k["t0"], pi=pi25, seeds=np.array([0, 5], np.int64))
+    for s in (0, 5):
+        env = ref_psrs.PSRS_Exo(buf, nO=100, nA=5, o_split_func=split, o_combine_func=combine)
+        env.reset_sampler(seed=s)
+        obs_seq, rew_seq, row_seq, resets = [], [], [], []
+        ep, stop = 0, False
+        while not stop:
+            o = env.reset(seed=ep)
+            resets.append(-1 if o is None else int(o))
+            if o is None:
+                break
+            done = False
+            while not done:
+                o2, r2, done, info = env.step(pi25[split(o)[0]])
+                if o2 is None:
+                    stop = True
+                    break
+                obs_seq.append(int(o2))
+                rew_seq.append(float(r2))
+                row_seq.append(pid[(np.asarray(info["p"]).tobytes(), int(info["a"]), float(r2))])
+                o = o2
+            ep += 1
+        out[f"s{s}_obs"], out[f"s{s}_rew"], out[f"s{s}_rows"], out[f"s{s}_resets"] = (np.array(obs_seq, np.int64), np.array(rew_seq),
+                                                                                    np.array(row_seq, np.int64), np.array(resets, np.int64))
+    np.savez_compressed(os.path.join(OUT, "exo_iid_2k.npz"), **out)
+    print(f"{'exo_iid_2k':28s} N={N:6d}  steps {len(out['s0_obs'])}, {len(out['s5_obs'])}")
+
     # ---- encoders ----
     cp = synth.cartpole_log(4096, seed=11)
     obs = cp["observations"].copy()

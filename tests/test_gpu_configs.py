@@ -238,3 +238,45 @@ def test_queue_evaluator_golden(name, gpu):
             if d["in_done"][row]:
                 env.reset()
     assert got == d[f"s{s}_rows"].tolist()
+
+
+def test_psrs_exo_golden(gpu):
+    """PSRS_Exo (psrs.py:59-117) under the evalMC-style protocol (reset(seed=episode) re-seeds the rejection stream):
+    observations, rewards and accepted s-rows equal the reference's."""
+    from common import load
+    from rl_offline_simulation_amd.evaluators import PSRS_Exo
+    d = load("exo_iid_2k")
+    split = lambda o: (o // 4, o % 4)
+    combine = lambda s, x: s * 4 + x
+    N = len(d["in_o"])
+    p_rows = [np.array(d["in_p_log"][i]) for i in range(N)]
+    pid = {(p_rows[i].tobytes(), int(d["in_a"][i]), float(d["in_r"][i])): i for i in range(N)}
+    buf = [(int(d["in_o"][i]), int(d["in_a"][i]), float(d["in_r"][i]), int(d["in_o_next"][i]), bool(d["in_done"][i]), p_rows[i],
+            {"t": 0 if d["in_t0"][i] else 1}) for i in range(N)]
+    env = PSRS_Exo(buf, nO=100, nA=5, o_split_func=split, o_combine_func=combine)
+    pi = d["pi"]
+    for s in d["seeds"]:
+        s = int(s)
+        env.reset_sampler(seed=s)
+        obs_seq, rew_seq, row_seq, resets = [], [], [], []
+        ep, stop = 0, False
+        while not stop:
+            o = env.reset(seed=ep)
+            resets.append(-1 if o is None else int(o))
+            if o is None:
+                break
+            done = False
+            while not done:
+                o2, r2, done, info = env.step(pi[split(o)[0]])
+                if o2 is None:
+                    stop = True
+                    break
+                obs_seq.append(int(o2))
+                rew_seq.append(float(r2))
+                row_seq.append(pid[(np.asarray(info["p"]).tobytes(), int(info["a"]), float(r2))])
+                o = o2
+            ep += 1
+        assert resets == d[f"s{s}_resets"].tolist()
+        assert row_seq == d[f"s{s}_rows"].tolist()
+        assert obs_seq == d[f"s{s}_obs"].tolist()
+        assert np.array_equal(np.array(rew_seq), d[f"s{s}_rew"])
