@@ -72,6 +72,8 @@ typedef struct offsim_table {
     int64_t N0;               /* rows with step == 0 (all rows if `steps` is absent, data.py:72) */
     const int32_t *init_slot; /* [N0]   slot of the k-th initial row, buffer order (psrs.py:22) */
     const int32_t *init_orig; /* [N0]   its row in the caller's buffer                          */
+    int64_t max_seg;          /* longest state segment (max of seg_off[s+1]-seg_off[s]); 0 = unknown:
+                                 the shuffle then sizes its LDS for the worst case (65536 rows)      */
 } offsim_table;
 
 /* State of R independent simulated rollouts (one PSRS env each).  Owned by the caller. */

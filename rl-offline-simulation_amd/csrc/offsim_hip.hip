@@ -13,10 +13,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "offsim.h"
 #include "pcg64_dev.hpp"
+#include "shuffle_wave.hpp"
 
 using namespace offsim;
 
@@ -326,6 +328,34 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
     if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");
     if (n_perm == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
+    static const bool legacy = getenv("OFFSIM_SHUFFLE_LEGACY") != nullptr;  // the one-lane-per-chain kernel (A/B measurements only)
+    if (!legacy) {
+        // wave-parallel exact Fisher-Yates (shuffle_wave.hpp): one workgroup per chain
+        const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
+        const uint32_t max_small = max_seg < SHUF_CAP16 ? max_seg : SHUF_CAP16;  // longest state segment that can live in LDS
+        uint32_t need16 = max_small;
+        if (t->N0 <= (int64_t)SHUF_CAP16 && (uint32_t)t->N0 > need16) need16 = (uint32_t)t->N0;
+        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need16 * 2 + 15) & ~(size_t)15);
+        const size_t lds32 = shuf_fixed_lds_bytes();
+        const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
+        if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_shuffle_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        static const int dbg_mode = getenv("OFFSIM_SHUFFLE_DBG") ? atoi(getenv("OFFSIM_SHUFFLE_DBG")) : 0;  // stage timing experiments (results are wrong)
+        const bool any_big = max_seg > SHUF_CAP16 || t->N0 > (int64_t)SHUF_CAP16;
+        if (any_big) {  // first: these chains are the long ones
+            hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), lds32, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
+                               n_perm, perm_out, init_perm_out, SHUF_CAP16, dbg_mode);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds, n_perm,
+                           perm_out, init_perm_out, SHUF_CAP16, dbg_mode);
+        LAUNCH_CHECK();
+        return OFFSIM_OK;
+    }
     // start from table order: perm[r][g] = g, init_perm[r][k] = k
     if (t->N > 0) {
         int64_t total = t->N * n_perm;
