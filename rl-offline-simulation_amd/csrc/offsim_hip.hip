@@ -335,7 +335,7 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
         const uint32_t max_small = max_seg < SHUF_CAP16 ? max_seg : SHUF_CAP16;  // longest state segment that can live in LDS
         uint32_t need16 = max_small;
         if (t->N0 <= (int64_t)SHUF_CAP16 && (uint32_t)t->N0 > need16) need16 = (uint32_t)t->N0;
-        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need16 * 2 + 15) & ~(size_t)15) + 144;  // + 64 dummy entries behind the segment
+        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need16 * 2 + 15) & ~(size_t)15) + 16;
         const size_t lds32 = shuf_fixed_lds_bytes();
         const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
         if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");

@@ -3,24 +3,23 @@
 // NumPy's Generator.shuffle of a list is   for i = n-1 .. 1:  j = random_interval(i);  swap(x[i], x[j])
 // with random_interval = masked rejection on buffered 32-bit halves of PCG64 outputs.  The chain looks strictly
 // sequential, and the first kernel ran it that way (one lane per chain, random 4-byte swaps in HBM: two 64-byte
-// sectors moved per swap, ~2e10 swaps/s at the random-sector limit of the memory system).  But nothing in it
-// depends on the DATA except the swaps themselves:
-//   - which draws are accepted, the step i each accepted draw serves and its partner j are functions of the random
-//     stream only, and 64 consecutive draws can be classified at once: draw l is accepted iff v_l <= i - (#accepts
-//     before l).  Start from the optimistic set {v_l <= i}, take prefix counts with ballot/mbcnt, and strike the
-//     first lane whose test fails (its prefix is exact, so it is a true reject) until none fails: usually zero
-//     rounds, since a lane can only fail when v_l lies within 64 of i;
-//   - 64 consecutive swaps commute unless two of them touch a common position.  A partner that lies inside the
-//     batch's own range of i (j_l == i_m, m later) is found by arithmetic and becomes a cut in front of lane m; two
-//     equal partners are found when the swaps are applied, by writing lane-id tags to the partner positions and
-//     reading them back.  Swaps are applied segment by segment in lane order, so the result is bit-identical to the
-//     sequential chain.
+// sectors moved per swap, ~2e10 swaps/s at the random-sector limit of the memory system).  But it factors:
+//   1. the sequence j(n-1), j(n-2), ..., j(1) is a function of the random stream only.  64 consecutive draws are
+//      classified at once: draw l is accepted iff v_l <= i - (#accepts before l).  Start from the optimistic set
+//      {v_l <= i}, take prefix counts with ballot/mbcnt, and strike the first lane whose test fails (its prefix is
+//      exact, so it is a true reject) until none fails -- usually zero rounds, a lane can only fail when v_l lies
+//      within 64 of i.  The accepted values, compacted in order, ARE the j sequence;
+//   2. 64 consecutive swaps (i, j(i)), i = t .. t-63, commute unless two of them touch a common position: either a
+//      partner lies in the group's own range of i (j(i) == i' for a later i': plain arithmetic, the later swap is
+//      lane t - j(i)), or two partners are equal (found by writing lane-id tags to the partner positions and reading
+//      them back).  A group with neither is applied in one LDS round trip; otherwise it is applied in pieces, in
+//      lane order, so the result is bit-identical to the sequential chain.
 // So one workgroup owns one chain, keeps the queue segment in LDS (16-bit entries, <= 65536 rows: the whole chain
 // runs at LDS latency and the only HBM traffic is the final coalesced write of the permutation), and splits the
-// work over four wavefronts connected by LDS queues:
-//     G  (two of them, alternate blocks) raw 32-bit draws: PCG64 jump-ahead, one 64-bit output per lane  -> ring
-//     C  classifies 2 x 64 draws per iteration: accepted masks, (i, j) per lane, cut masks                -> records
-//     A  applies the swaps of each record to the segment
+// work over four wavefronts connected by LDS rings:
+//     G  (two of them, alternate blocks) raw 32-bit draws: PCG64 jump-ahead, one 64-bit output per lane  -> draw ring
+//     C  classifies 2 x 64 draws per iteration and appends the accepted values                             -> j ring
+//     A  applies 64 steps per iteration to the segment
 // Segments that do not fit (the init queue of a big log, states with > 65536 rows) use the same roles with the
 // segment left in global memory (32-bit entries, in place).
 #pragma once
@@ -32,20 +31,15 @@
 namespace offsim {
 
 #define SHUF_RG 2048u  // raw draws in the ring (power of two, multiple of 128)
-#define SHUF_QB 16u    // batch records in flight (power of two)
-#define SHUF_CAP16 65472u  // rows of a segment kept in LDS (16-bit indices, 64 dummy entries behind it)
-enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_QHEAD = 3, SH_QTAIL = 4, SH_DONE = 5 };  // words of the control block
+#define SHUF_SQ 1024u  // partners in the j ring (power of two, >= 3 * 128)
+#define SHUF_CAP16 65536u
+enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5 };  // words of the control block
 
-// explicit LDS address space: keeps every queue / segment access a ds_* instruction (a generic pointer would make
+// explicit LDS address space: keeps every ring / segment access a ds_* instruction (a generic pointer would make
 // them flat_* operations, which also tie up the vector-memory counter)
 typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
 typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
 typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64;
-typedef __attribute__((address_space(3))) volatile unsigned char lds_vu8;
-typedef uint32_t sh_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t sh_u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) volatile sh_u32x4 lds_vu32x4;
-typedef __attribute__((address_space(3))) volatile sh_u32x2 lds_vu32x2;
 
 __device__ __forceinline__ uint32_t sh_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }  // (readfirstlane returns int)
 __device__ __forceinline__ uint32_t sh_ld(lds_vu32 *p) { return sh_rfl(*p); }
@@ -56,8 +50,8 @@ __device__ __forceinline__ int sh_rank(uint64_t m) {  // set bits of m in front 
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// LDS layout: [ctrl 16 w][ring RG w][record headers QB x 4 w][records QB x 128 w][segment]
-constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_QB * 4u + SHUF_QB * 128u); }
+// LDS layout: [ctrl 16 w][draw ring RG w][j ring SQ w + 64 w trash][64 w tag winners][segment]
+constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_SQ + 64u + 64u); }
 
 // LDS16 = true : segments with 1 <= n <= cap16 rows, kept in LDS as 16-bit local indices
 // LDS16 = false: segments with n > cap16 rows, shuffled in place in global memory (32-bit)
@@ -68,9 +62,9 @@ __global__ void __launch_bounds__(256)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
-    lds_vu32 *qhdr = ring + SHUF_RG;       // {accepted mask lo, hi, cut mask lo, hi} per record
-    lds_vu32 *qrec = qhdr + SHUF_QB * 4u;  // per lane {position i, partner j}: byte offsets (LDS16) or indices
-    lds_vu16 *x16 = (lds_vu16 *)(qrec + SHUF_QB * 128u);
+    lds_vu32 *jq = ring + SHUF_RG;  // partners in step order; [SQ .. SQ+63] takes the stores of rejected lanes
+    lds_vu32 *win = jq + SHUF_SQ + 64u;  // A: "lane l won a tag" (all zero between uses)
+    lds_vu16 *x16 = (lds_vu16 *)(win + 64u);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
     // chain of this workgroup: the init queue first (usually the longest chain), then state by state
@@ -92,10 +86,9 @@ __global__ void __launch_bounds__(256)
     if (n == 0) return;
     if (LDS16 ? (n > cap16) : (n <= cap16)) return;
     volatile uint32_t *x32 = (volatile uint32_t *)xg;
-    const uint32_t dummy_idx = ((n + 1u) & ~1u) + (uint32_t)lane;  // LDS16: this lane's private entry behind the segment (< 65536)
-    const uint32_t dummy_pk = (dummy_idx << 16) | dummy_idx;
 
     if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0;
+    if (threadIdx.x < 64u) win[threadIdx.x] = 0;
     if (LDS16) {  // identity, two entries per lane and store
         __attribute__((address_space(3))) uint32_t *xw = (__attribute__((address_space(3))) uint32_t *)x16;
         for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) xw[k] = ((2u * k + 1u) << 16) | (2u * k);
@@ -104,7 +97,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
 
-    // Queue protocol.  All queues live in LDS, every role is one wavefront, and the LDS unit executes the DS
+    // Ring protocol.  The rings live in LDS, every role is one wavefront, and the LDS unit executes the DS
     // instructions of a wavefront in issue order: data written before a counter is visible before the counter, and a
     // read issued after a counter was seen comes after the data.  So the counters are plain volatile words (the
     // volatile qualifier keeps the compiler from reordering them) and no s_waitcnt is spent on publishing.
@@ -138,10 +131,9 @@ __global__ void __launch_bounds__(256)
                 sh_st(ctrl + (g ? SH_GEN1 : SH_GEN0), done_blocks);
             }
         } else if (wave == 1) {
-            // ---------------- C: classify, 2 x 64 draws per iteration.  The second batch starts from i2 = i - accepts of
-            // the first, so the wavefront has two independent instruction streams; conflicts do not stop a batch (they
-            // become cut masks for A), so every iteration consumes its 128 draws except at a mask boundary.
-            uint32_t i = n - 1u, c = 0, avail = 0, qh = 0, qt = 0, c_pub = 0;
+            // ---------------- C: the j sequence, 2 x 64 draws per iteration.  The second batch starts from i2 = i - accepts
+            // of the first, so the wavefront has two independent instruction streams.
+            uint32_t i = n - 1u, c = 0, avail = 0, fill = 0, tail = 0, c_pub = 0;
             uint32_t mask = 0xffffffffu >> __builtin_clz(i);
             int lowpow = (int)((mask >> 1) + 1u);  // steps below this index use the next smaller mask
             auto wait_draws = [&](uint32_t upto) {
@@ -152,76 +144,19 @@ __global__ void __launch_bounds__(256)
                     if (upto > avail) __builtin_amdgcn_s_sleep(1);
                 }
             };
-            auto wait_room = [&](uint32_t slots) {
-                while (qh + slots - qt > SHUF_QB) {
-                    qt = sh_ld(ctrl + SH_QTAIL);
-                    if (qh + slots - qt > SHUF_QB) __builtin_amdgcn_s_sleep(1);
+            auto wait_room = [&](uint32_t upto) {  // the j ring may hold entries [tail, tail + SQ)
+                while (upto - tail > SHUF_SQ) {
+                    tail = sh_ld(ctrl + SH_TAIL);
+                    if (upto - tail > SHUF_SQ) __builtin_amdgcn_s_sleep(1);
                 }
             };
             // strike optimistic accepts that do not hold, first one first, until all hold
-            auto settle = [&](uint64_t &bal, int &il, uint32_t v, uint32_t ib) {
-                uint64_t f = bal & __ballot((int)v > il);
+            auto settle = [&](uint64_t &bal, int &rk, uint32_t v, uint32_t ib) {
+                uint64_t f = bal & __ballot((int)v > (int)ib - rk);
                 while (f) {
                     bal &= ~(1ull << sh_ff1(f));
-                    il = (int)ib - sh_rank(bal);
-                    f = bal & __ballot((int)v > il);
-                }
-            };
-            // partner inside the batch's own range of i: the later swap (the lane whose i equals that partner) must see the
-            // earlier one -> cut in front of it
-            auto cut_mask = [&](uint64_t bal, int il, uint32_t v, uint32_t ib) -> uint64_t {
-                uint64_t confl = bal & __ballot((int)v < il) & __ballot((int)v > (int)ib - (int)__popcll(bal));
-                uint64_t cuts = 0;
-                while (confl) {
-                    const int vf = (int)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(confl));
-                    cuts |= bal & __ballot(il == vf);
-                    confl &= confl - 1ull;
-                }
-                return cuts;
-            };
-            // LDS16 records are mask-free: one word (i << 16 | j) per lane, and a lane that has no swap in the record swaps a
-            // private dummy entry behind the segment with itself; a batch with cuts is written as one record per piece.  So A
-            // runs every record on all 64 lanes without masks or headers.  After settling, the accepted lanes are exactly
-            // those with v <= il, so the common case needs no lane mask here either.  (The in-place global-memory variant
-            // keeps masks: header {accepted, cuts}.)
-            auto put16 = [&](uint32_t packed) {
-                while (qh + 1u - qt > SHUF_QB) {
-                    qt = sh_ld(ctrl + SH_QTAIL);
-                    if (qh + 1u - qt > SHUF_QB) __builtin_amdgcn_s_sleep(1);
-                }
-                qrec[(qh & (SHUF_QB - 1u)) * 128u + (uint32_t)lane] = packed;
-                qh++;
-                sh_st(ctrl + SH_QHEAD, qh);
-            };
-            auto emit = [&](int il, uint32_t v, uint64_t accm, uint64_t cuts, bool whole) {  // whole: accm = every lane with v <= il
-                if (LDS16) {
-                    const uint32_t pk = ((uint32_t)il << 16) | v;
-                    if (__builtin_expect(cuts == 0ull && whole, 1)) {
-                        put16((int)v <= il ? pk : dummy_pk);
-                    } else {
-                        uint64_t rem = accm;
-                        while (rem) {
-                            uint64_t seg = rem;
-                            const uint64_t cm = cuts & rem & (rem - 1ull);  // cuts in front of lanes other than the first remaining one
-                            if (cm) seg = rem & ((cm & (0ull - cm)) - 1ull);
-                            put16(((seg >> lane) & 1ull) ? pk : dummy_pk);
-                            rem &= ~seg;
-                        }
-                    }
-                } else {
-                    const uint32_t slot = qh & (SHUF_QB - 1u);
-                    sh_u32x2 rv;
-                    rv.x = (uint32_t)il;
-                    rv.y = v;
-                    *(lds_vu32x2 *)(qrec + slot * 128u + 2u * (uint32_t)lane) = rv;
-                    sh_u32x4 hv;
-                    hv.x = (uint32_t)accm;
-                    hv.y = (uint32_t)(accm >> 32);
-                    hv.z = (uint32_t)cuts;
-                    hv.w = (uint32_t)(cuts >> 32);
-                    *(lds_vu32x4 *)(qhdr + slot * 4u) = hv;
-                    qh++;
-                    sh_st(ctrl + SH_QHEAD, qh);
+                    rk = sh_rank(bal);
+                    f = bal & __ballot((int)v > (int)ib - rk);
                 }
             };
             wait_draws(128u);
@@ -232,23 +167,30 @@ __global__ void __launch_bounds__(256)
                 const uint32_t p2 = ring[(c + 192u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 const uint32_t v1 = r1 & mask, v2 = r2 & mask;
                 uint64_t bal1 = __ballot(v1 <= i);  // optimistic: accepted if no earlier lane of the batch had been accepted
-                uint32_t i2 = i - (uint32_t)__popcll(bal1);
+                uint32_t n1 = (uint32_t)__popcll(bal1);
+                uint32_t i2 = i - n1;
                 uint64_t bal2 = __ballot((int)v2 <= (int)i2);
-                int il1 = (int)i - sh_rank(bal1);   // the step a lane's draw serves
-                int il2 = (int)i2 - sh_rank(bal2);
-                if (__builtin_expect((bal1 & __ballot((int)v1 > il1)) != 0ull, 0)) {
-                    settle(bal1, il1, v1, i);
-                    i2 = i - (uint32_t)__popcll(bal1);
+                int rk1 = sh_rank(bal1), rk2 = sh_rank(bal2);  // accepts in front of the lane: its draw serves step i - rk
+                if (__builtin_expect((bal1 & __ballot((int)v1 > (int)i - rk1)) != 0ull, 0)) {
+                    settle(bal1, rk1, v1, i);
+                    n1 = (uint32_t)__popcll(bal1);
+                    i2 = i - n1;
                     bal2 = __ballot((int)v2 <= (int)i2);
-                    il2 = (int)i2 - sh_rank(bal2);
+                    rk2 = sh_rank(bal2);
                 }
-                if (__builtin_expect((bal2 & __ballot((int)v2 > il2)) != 0ull, 0)) settle(bal2, il2, v2, i2);
-                const int i_new = (int)i2 - __popcll(bal2);
+                if (__builtin_expect((bal2 & __ballot((int)v2 > (int)i2 - rk2)) != 0ull, 0)) settle(bal2, rk2, v2, i2);
+                const uint32_t n2 = (uint32_t)__popcll(bal2);
+                const int i_new = (int)i2 - (int)n2;
                 if (__builtin_expect(i_new >= lowpow, 1)) {
-                    const uint64_t cuts1 = cut_mask(bal1, il1, v1, i), cuts2 = cut_mask(bal2, il2, v2, i2);
-                    if (!LDS16) wait_room(2u);
-                    if (bal1) emit(il1, v1, bal1, cuts1, true);
-                    if (bal2) emit(il2, v2, bal2, cuts2, true);
+                    // after settling the accepted lanes are exactly those with v <= i - rk: append them in order; the
+                    // others store into the trash words behind the ring
+                    wait_room(fill + n1 + n2);
+                    const uint32_t a1 = (int)v1 <= (int)i - rk1 ? ((fill + (uint32_t)rk1) & (SHUF_SQ - 1u)) : SHUF_SQ + (uint32_t)lane;
+                    const uint32_t a2 = (int)v2 <= (int)i2 - rk2 ? ((fill + n1 + (uint32_t)rk2) & (SHUF_SQ - 1u)) : SHUF_SQ + (uint32_t)lane;
+                    jq[a1] = v1;
+                    jq[a2] = v2;
+                    fill += n1 + n2;
+                    sh_st(ctrl + SH_FILL, fill);
                     i = (uint32_t)i_new;
                     c += 128u;
                     r1 = p1;
@@ -256,15 +198,15 @@ __global__ void __launch_bounds__(256)
                 } else {
                     // a mask boundary (or the end of the chain) inside the pair: batch 1 only, and only the draws -- accepted
                     // or not -- of steps at or above the boundary
-                    const uint64_t lowm = __ballot(il1 < lowpow);
+                    const uint64_t lowm = __ballot((int)i - rk1 < lowpow);
                     const uint64_t below = (lowm & (0ull - lowm)) - 1ull;  // lanes in front of the first such draw (all if none)
                     const uint64_t acc = bal1 & below;
-                    if (acc) {
-                        const uint64_t cuts = cut_mask(acc, il1, v1, i);
-                        if (!LDS16) wait_room(1u);
-                        emit(il1, v1, acc, cuts, false);
-                    }
-                    i -= (uint32_t)__popcll(acc);
+                    const uint32_t na = (uint32_t)__popcll(acc);
+                    wait_room(fill + na);
+                    jq[((acc >> lane) & 1ull) ? ((fill + (uint32_t)rk1) & (SHUF_SQ - 1u)) : SHUF_SQ + (uint32_t)lane] = v1;
+                    fill += na;
+                    sh_st(ctrl + SH_FILL, fill);
+                    i -= na;
                     c += (uint32_t)__popcll(below);
                     if ((int)i < lowpow && i >= 1u) {  // crossed a power of two: the mask shrinks
                         mask = 0xffffffffu >> __builtin_clz(i);
@@ -274,145 +216,96 @@ __global__ void __launch_bounds__(256)
                     r1 = ring[(c + (uint32_t)lane) & (SHUF_RG - 1u)];
                     r2 = ring[(c + 64u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 }
-                if (c - c_pub >= 256u) {  // the ring is 2048 draws deep: G does not need every step
+                if (c - c_pub >= 256u) {  // the draw ring is 2048 deep: G does not need every step
                     c_pub = c;
                     sh_st(ctrl + SH_CPUB, c);
                 }
             }
-            if (!LDS16) {  // end marker: a record with an empty mask (LDS16: A stops when DONE is set and the queue is empty)
-                wait_room(1u);
-                *(lds_vu64 *)(qhdr + (qh & (SHUF_QB - 1u)) * 4u) = 0ull;
-                qh++;
-                sh_st(ctrl + SH_QHEAD, qh);
-            }
             sh_st(ctrl + SH_DONE, 1u);
         } else {
-            // ---------------- A: apply the records in order, each one segment by segment (cut masks) and, inside a
-            // segment, as far as the partners are distinct (lane-id tags written to the partner positions and read back)
-            uint32_t qt = 0, qh = 0;
-            lds_vu8 *xb = (lds_vu8 *)x16;
-            if (LDS16) {
-                // mask-free records (see emit): all 64 lanes swap, lanes without a swap exchange their dummy entry with itself
-                for (;;) {
-                    bool fin = false;
-                    while (qt == qh) {
-                        qh = sh_ld(ctrl + SH_QHEAD);
-                        if (qt != qh) break;
-                        if (sh_ld(ctrl + SH_DONE)) {  // C sets DONE after its last record: look once more, then stop
-                            qh = sh_ld(ctrl + SH_QHEAD);
-                            fin = qt == qh;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (fin) break;
-                    const uint32_t rv = qrec[(qt & (SHUF_QB - 1u)) * 128u + (uint32_t)lane];
-                    qt++;
-                    sh_st(ctrl + SH_QTAIL, qt);  // issued after the read of the record: its slot may be reused
-                    if (dbg_mode == 1) continue;
-                    const uint32_t il = (rv >> 15) & 0x1fffeu, v = (rv & 0xffffu) << 1;  // byte offsets
-                    const uint32_t a = *(lds_vu16 *)(xb + il);
-                    const uint32_t b = *(lds_vu16 *)(xb + v);
-                    *(lds_vu16 *)(xb + v) = (uint16_t)lane;  // tag: two lanes with the same partner see one winner
-                    const uint32_t tg = *(lds_vu16 *)(xb + v);
-                    if (__builtin_expect(__ballot(tg != (uint32_t)lane) == 0ull, 1)) {
-                        *(lds_vu16 *)(xb + il) = (uint16_t)b;
-                        *(lds_vu16 *)(xb + v) = (uint16_t)a;
-                        continue;
-                    }
-                    // equal partners somewhere: take the tags back and apply the record piecewise
-                    *(lds_vu16 *)(xb + v) = (uint16_t)b;
-                    uint64_t rem = __ballot((rv >> 16) != dummy_idx);
-                    while (rem) {
-                        const bool act = (rem >> lane) & 1ull;
-                        uint32_t a2 = 0, b2 = 0, t2 = (uint32_t)lane;
-                        if (act) {
-                            a2 = *(lds_vu16 *)(xb + il);
-                            b2 = *(lds_vu16 *)(xb + v);
-                            *(lds_vu16 *)(xb + v) = (uint16_t)lane;
-                            t2 = *(lds_vu16 *)(xb + v);
-                        }
-                        const uint64_t F = __ballot(act && t2 != (uint32_t)lane);
-                        uint64_t proc = rem;
-                        if (F) {  // stop in front of the second lane of the earliest group of equal partners
-                            uint64_t Wn = 0, FF = F;
-                            while (FF) {
-                                Wn |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)t2, (int)sh_ff1(FF));
-                                FF &= FF - 1ull;
-                            }
-                            const uint64_t D = F | Wn;
-                            const uint64_t D2 = D & (D - 1ull);
-                            proc = rem & sh_lowmask(sh_ff1(D2));
-                            if (act && !((proc >> lane) & 1ull)) *(lds_vu16 *)(xb + v) = (uint16_t)b2;  // not this time: take the tag back
-                        }
-                        if ((proc >> lane) & 1ull) {
-                            *(lds_vu16 *)(xb + il) = (uint16_t)b2;
-                            *(lds_vu16 *)(xb + v) = (uint16_t)a2;
-                        }
-                        rem &= ~proc;
+            // ---------------- A: apply, 64 consecutive steps i_top, i_top - 1, ... per iteration (lane l: step i_top - l).
+            // One tag round finds every pair of equal partners; together with the arithmetic cuts that gives all the places
+            // where the group has to be split, and the pieces are then plain conflict-free swaps.
+            uint32_t i_top = n - 1u, done = 0, fill = 0;
+            auto xrd = [&](uint32_t k) -> uint32_t { return LDS16 ? (uint32_t)x16[k] : x32[k]; };
+            auto xwr = [&](uint32_t k, uint32_t val) {
+                if (LDS16) x16[k] = (uint16_t)val;
+                else x32[k] = val;
+            };
+            // the piecewise path: lanes < cnt hold (il, v); their tags are still in place, b = the values under the tags,
+            // confl = lanes whose partner is a later step of the group, F = lanes that lost a tag
+            auto piecewise = [&](uint32_t cnt, uint32_t i_first, uint32_t il, uint32_t v, uint32_t b, uint32_t tg, uint64_t confl, uint64_t F) {
+                const bool in = (uint32_t)lane < cnt;
+                if (in) xwr(v, b);  // take the tags back
+                uint64_t cuts = 0;
+                while (confl) {
+                    cuts |= 1ull << (i_first - sh_rfl((uint32_t)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(confl))));  // the lane that owns step v
+                    confl &= confl - 1ull;
+                }
+                if (F) {  // every lane with a shared partner except the first of them: losers and the winners they saw
+                    const bool lost = tg != (uint32_t)lane;
+                    if (lost) win[tg] = 1u;
+                    const uint32_t w = win[(uint32_t)lane];
+                    if (lost) win[tg] = 0u;
+                    const uint64_t D = F | __ballot(w != 0u);
+                    cuts |= D & (D - 1ull);
+                }
+                // piece number of every lane = cuts at or in front of it; the pieces are applied in order
+                const uint32_t pid = in ? (uint32_t)sh_rank(cuts) + (uint32_t)((cuts >> lane) & 1ull) : 0xffffffffu;
+                const uint32_t n_pieces = (uint32_t)__popcll(cuts & sh_lowmask(cnt) & ~1ull) + 1u;
+                for (uint32_t pc = (uint32_t)(cuts & 1ull); pc < n_pieces + (uint32_t)(cuts & 1ull); pc++) {
+                    if (pid == pc) {
+                        const uint32_t a2 = xrd(il), b2 = xrd(v);
+                        xwr(il, b2);
+                        xwr(v, a2);
                     }
                 }
-            } else
-            for (;;) {
-                while (qt == qh) {
-                    qh = sh_ld(ctrl + SH_QHEAD);
-                    if (qt == qh) __builtin_amdgcn_s_sleep(1);
+            };
+            // full groups: no lane masks anywhere on the common path.  (Fetching the next group's partners early was
+            // measured slower: this wavefront is bound by the instructions it issues, not by the LDS round trips.)
+            while (i_top >= 64u) {
+                while (fill - done < 64u) {
+                    fill = sh_ld(ctrl + SH_FILL);
+                    if (fill - done < 64u) __builtin_amdgcn_s_sleep(1);
                 }
-                const uint32_t slot = qt & (SHUF_QB - 1u);
-                const sh_u32x4 hv = *(lds_vu32x4 *)(qhdr + slot * 4u);
-                const sh_u32x2 rv = *(lds_vu32x2 *)(qrec + slot * 128u + 2u * (uint32_t)lane);
-                const uint64_t accm = ((uint64_t)sh_rfl(hv.y) << 32) | sh_rfl(hv.x);
-                const uint64_t cuts = ((uint64_t)sh_rfl(hv.w) << 32) | sh_rfl(hv.z);
-                if (!accm) break;
-                const uint32_t il = rv.x, v = rv.y;
-                qt++;
-                sh_st(ctrl + SH_QTAIL, qt);  // issued after the reads of the record: its slot may be reused
-                uint64_t rem = dbg_mode == 1 ? 0ull : accm;
-                while (rem) {
-                    uint64_t seg = rem;
-                    const uint64_t cm = cuts & rem & (rem - 1ull);  // cuts in front of lanes other than the first remaining one
-                    if (__builtin_expect(cm != 0ull, 0)) seg = rem & ((cm & (0ull - cm)) - 1ull);
-                    const bool act = (seg >> lane) & 1ull;
-                    uint32_t a = 0, b = 0, tg = (uint32_t)lane;
-                    if (act) {
-                        if (LDS16) {
-                            a = *(lds_vu16 *)(xb + il);
-                            b = *(lds_vu16 *)(xb + v);
-                            *(lds_vu16 *)(xb + v) = (uint16_t)lane;  // tag: two lanes with the same partner see one winner
-                            tg = *(lds_vu16 *)(xb + v);
-                        } else {
-                            a = x32[il];
-                            b = x32[v];
-                            x32[v] = (uint32_t)lane;
-                            tg = x32[v];
-                        }
+                const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
+                done += 64u;
+                sh_st(ctrl + SH_TAIL, done);  // issued after the read: the entries may be overwritten
+                const uint32_t i_first = i_top;
+                const uint32_t il = i_first - (uint32_t)lane;
+                i_top -= 64u;
+                if (dbg_mode == 1) continue;
+                // a partner inside the group's own later steps: cut in front of the lane that owns that step
+                const uint64_t confl = __ballot(v < il) & __ballot(v > i_top);
+                const uint32_t a = xrd(il), b = xrd(v);
+                xwr(v, (uint32_t)lane);  // tag: lanes with the same partner see one winner
+                const uint32_t tg = xrd(v);
+                const uint64_t F = __ballot(tg != (uint32_t)lane);  // lanes that lost a tag
+                if (__builtin_expect((confl | F) == 0ull, 1)) {
+                    xwr(il, b);
+                    xwr(v, a);
+                } else {
+                    piecewise(64u, i_first, il, v, b, tg, confl, F);
+                }
+            }
+            if (i_top >= 1u) {  // the last, partial group
+                const uint32_t cnt = i_top;
+                while (fill - done < cnt) {
+                    fill = sh_ld(ctrl + SH_FILL);
+                    if (fill - done < cnt) __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
+                const uint32_t il = i_top - (uint32_t)lane;
+                const bool in = (uint32_t)lane < cnt;
+                if (dbg_mode != 1) {
+                    const uint64_t confl = __ballot(in && v < il && v >= 1u);
+                    uint32_t b = 0, tg = (uint32_t)lane;
+                    if (in) {
+                        b = xrd(v);
+                        xwr(v, (uint32_t)lane);
+                        tg = xrd(v);
                     }
-                    const uint64_t F = __ballot(act && tg != (uint32_t)lane);
-                    uint64_t proc = seg;
-                    if (__builtin_expect(F != 0ull, 0)) {  // equal partners: stop in front of the second lane of the earliest group
-                        uint64_t Wn = 0, FF = F;
-                        while (FF) {
-                            Wn |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)tg, (int)sh_ff1(FF));
-                            FF &= FF - 1ull;
-                        }
-                        const uint64_t D = F | Wn;
-                        const uint64_t D2 = D & (D - 1ull);
-                        proc = seg & sh_lowmask(sh_ff1(D2));
-                        if (act && !((proc >> lane) & 1ull)) {  // not this time: take the tag back
-                            if (LDS16) *(lds_vu16 *)(xb + v) = (uint16_t)b;
-                            else x32[v] = b;
-                        }
-                    }
-                    if ((proc >> lane) & 1ull) {
-                        if (LDS16) {
-                            *(lds_vu16 *)(xb + il) = (uint16_t)b;
-                            *(lds_vu16 *)(xb + v) = (uint16_t)a;
-                        } else {
-                            x32[il] = b;
-                            x32[v] = a;
-                        }
-                    }
-                    rem &= ~proc;
+                    piecewise(cnt, i_top, il, v, b, tg, confl, __ballot(tg != (uint32_t)lane));
                 }
             }
         }
