@@ -1016,7 +1016,8 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     const int rounds = (t->n_slots + 63) / 64;
 #define LAUNCH_WIN(W, ROUNDS)                                                                                         \
     do {                                                                                                              \
-        size_t lds = (((size_t)(t->n_slots + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * ((size_t)t->n_slots * (W) * 4 + OFFSIM_RING * 4 + (size_t)t->n_slots * 16);                                \
+        size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) +                                      \
+                     (size_t)waves * ((OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 + 511) & ~(size_t)511); \
         if (trace)                                                                                                    \
             hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \

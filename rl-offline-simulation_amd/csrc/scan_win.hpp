@@ -23,6 +23,10 @@
 
 namespace offsim {
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t scan_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) scan_u32x2 lds_u32x2;
+
 #define OFFSIM_RING 128  // draws kept ahead per rollout (power of two >= 2*64)
 #define OFFSIM_PH 64     // accepted steps per refill phase (lane i stages step i's reward)
 
@@ -106,12 +110,21 @@ __global__ void __launch_bounds__(256, 4)
     const int waves = blockDim.x / 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;  // wave id is uniform: keep it scalar
     const int n_slots = t.n_slots;
-    uint32_t *seg = (uint32_t *)lds_raw;
-    const uint32_t seg_bytes = ((uint32_t)(n_slots + 1) * 4 + 15u) & ~15u;
-    const uint32_t win_bytes = (uint32_t)n_slots * W * 4, wave_bytes = win_bytes + OFFSIM_RING * 4 + (uint32_t)n_slots * 16;
-    uint32_t *win = (uint32_t *)(lds_raw + seg_bytes + (size_t)wave * wave_bytes);
-    uint32_t *ring = (uint32_t *)((unsigned char *)win + win_bytes);
-    uint2 *meta = (uint2 *)(ring + OFFSIM_RING);     // .x = cur (candidates popped), .y = landed (window valid up to)
+    // Every per-wave region starts on a 512-byte LDS address: the draw ring (512 B) and the window rows (W*4 B each) are
+    // then naturally aligned, and the chain loop forms their addresses with one add-shift and one and-or.
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_byte *)lds_raw;
+    const uint32_t lds_pad = (0u - lds_base) & 511u;
+    uint32_t *seg = (uint32_t *)(lds_raw + lds_pad);
+    const uint32_t seg_bytes = ((uint32_t)(n_slots + 1) * 4 + 511u) & ~511u;
+    const uint32_t win_bytes = (uint32_t)n_slots * W * 4;
+    const uint32_t wave_bytes = (OFFSIM_RING * 4 + win_bytes + (uint32_t)n_slots * 16 + 511u) & ~511u;
+    const uint32_t ring_off = lds_base + lds_pad + seg_bytes + (uint32_t)wave * wave_bytes;  // LDS byte address of this wave's region
+    uint32_t *ring = (uint32_t *)(lds_raw + lds_pad + seg_bytes + (size_t)wave * wave_bytes);
+    uint32_t *win = ring + OFFSIM_RING;
+    const uint32_t win_off = ring_off + OFFSIM_RING * 4;
+    uint2 *meta = (uint2 *)((unsigned char *)win + win_bytes);  // .x = cur (candidates popped), .y = landed (window valid up to)
+    const uint32_t meta_off = win_off + win_bytes;
     uint32_t *fillq = (uint32_t *)(meta + n_slots);  // queue position up to which entries have been requested
     uint32_t *claim = fillq + n_slots;               // refill ownership: which lane requests for a state this tick
     for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg[i] = t.seg_off[i];
@@ -360,6 +373,7 @@ __global__ void __launch_bounds__(256, 4)
         // of the one scalar ALU that the CU's 16 rollouts share (the loop was scalar-issue bound)
         uint32_t vslot;
         asm("v_mov_b32 %0, %1" : "=v"(vslot) : "s"(slot));
+        uint32_t vrow = win_off + vslot * (uint32_t)(W * 4), vmeta = meta_off + vslot * 8u;  // LDS addresses of its window row and meta entry
         int vrel = lane - (int)nph;                       // lane - (steps logged this phase): the lane with 0 logs the next step
         const uint32_t nph_in = nph;
         int tick_b = (int)((TICK - 1u) - (nph & (TICK - 1u)));  // goes negative when a multiple of TICK steps has been logged
@@ -368,10 +382,9 @@ __global__ void __launch_bounds__(256, 4)
         do {
             const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop stops as "all rejected"
             const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
-            uint32_t wi = m.x % W + lane;  // ring position of candidate `lane`
-            wi = wi >= (uint32_t)W ? wi - W : wi;
-            wi = lane < W ? wi : 0u;
-            uint32_t dig = win[vslot * W + wi];
+            // candidate `lane` of the current state sits at ring position (cur + lane) mod W of its row (lanes >= W read
+            // some entry of the row and are masked below)
+            uint32_t dig = *(lds_u32 *)((((m.x + (uint32_t)lane) << 2) & (uint32_t)(W * 4 - 4)) | vrow);
             dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
             const uint32_t Tt = dig >> 11;
             many = __ballot(kt <= Tt);
@@ -384,7 +397,7 @@ __global__ void __launch_bounds__(256, 4)
             if (__builtin_expect(((macc >> (f & 63)) & 1ull) != 0ull, 1)) {
                 const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
                 const uint32_t v_pos = m.x + (uint32_t)f;
-                meta[vslot].x = v_pos + 1u;
+                *(lds_u32 *)vmeta = v_pos + 1u;  // meta[vslot].x
                 const bool mine = vrel == 0;
                 vrel -= 1;
                 uint32_t vdig;
@@ -399,8 +412,14 @@ __global__ void __launch_bounds__(256, 4)
                 }
                 tick_b -= 1;
                 vslot = vdig & 1023u;
-                kt = ring[(c + lane) & (OFFSIM_RING - 1)];  // fetched one step ahead: needs only the new draw count
-                m = meta[vslot];                           // and the next state
+                vrow = win_off + vslot * (uint32_t)(W * 4);
+                vmeta = meta_off + vslot * 8u;
+                kt = *(lds_u32 *)((((c + (uint32_t)lane) << 2) & (OFFSIM_RING * 4 - 4)) | ring_off);  // fetched one step ahead: needs only the new draw count
+                {
+                    const scan_u32x2 mv = *(lds_u32x2 *)vmeta;  // and the next state
+                    m.x = mv.x;
+                    m.y = mv.y;
+                }
                 last_dig = acc_dig;
                 // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
                 stop = ((acc_dig >> 10) & 1u) | (((uint32_t)tick_b | (gen_m64 - c)) >> 31);
