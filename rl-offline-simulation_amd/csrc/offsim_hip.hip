@@ -1017,7 +1017,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
 #define LAUNCH_WIN(W, ROUNDS)                                                                                         \
     do {                                                                                                              \
         size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) +                                      \
-                     (size_t)waves * ((OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 + 511) & ~(size_t)511); \
+                     (size_t)waves * ((OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 + OFFSIM_PH * 8 + (trace ? OFFSIM_PH * 4 : 0) + 511) & ~(size_t)511); \
         if (trace)                                                                                                    \
             hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \

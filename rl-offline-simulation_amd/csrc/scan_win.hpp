@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(256, 4)
     uint32_t *seg = (uint32_t *)(lds_raw + lds_pad);
     const uint32_t seg_bytes = ((uint32_t)(n_slots + 1) * 4 + 511u) & ~511u;
     const uint32_t win_bytes = (uint32_t)n_slots * W * 4;
-    const uint32_t wave_bytes = (OFFSIM_RING * 4 + win_bytes + (uint32_t)n_slots * 16 + 511u) & ~511u;
+    const uint32_t log_bytes = OFFSIM_PH * 8u + (TRACE ? OFFSIM_PH * 4u : 0u);  // per-phase step log (+ candidates popped per step)
+    const uint32_t wave_bytes = (OFFSIM_RING * 4 + win_bytes + (uint32_t)n_slots * 16 + log_bytes + 511u) & ~511u;
     const uint32_t ring_off = lds_base + lds_pad + seg_bytes + (uint32_t)wave * wave_bytes;  // LDS byte address of this wave's region
     uint32_t *ring = (uint32_t *)(lds_raw + lds_pad + seg_bytes + (size_t)wave * wave_bytes);
     uint32_t *win = ring + OFFSIM_RING;
@@ -127,6 +128,11 @@ __global__ void __launch_bounds__(256, 4)
     const uint32_t meta_off = win_off + win_bytes;
     uint32_t *fillq = (uint32_t *)(meta + n_slots);  // queue position up to which entries have been requested
     uint32_t *claim = fillq + n_slots;               // refill ownership: which lane requests for a state this tick
+    // step log of the current phase, entry i = {cursor behind the accepted candidate, digest with the z_next field
+    // replaced by the state the step left}: written by the chain loop with one LDS store per step (keeping it in
+    // per-lane registers cost five VALU instructions per step), read back lane = step by the refill pass and the flush
+    const uint32_t log_off = meta_off + (uint32_t)n_slots * 16u;
+    uint32_t *popq = (uint32_t *)(claim + n_slots) + OFFSIM_PH * 2;  // TRACE only
     for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg[i] = t.seg_off[i];
     __syncthreads();
     const int r = blockIdx.x * waves + wave;
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256, 4)
     }
     uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start (every examined candidate = one draw)
     auto gen_block = [&]() {
-        ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43);
+        ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43) << 11;  // top 21 bits, aligned with the digest's T21
         lane_state = pcg_apply(j64, lane_state);
         gen += 64;
     };
@@ -226,7 +232,15 @@ __global__ void __launch_bounds__(256, 4)
     uint32_t tt_chain = 0;               // accepted steps since the last episode end, as of the end of the last logged phase
     uint32_t ticks_done = 0;
     uint32_t slot_log = 0;  // (declared here: the refill pass reads the states the logged steps left)
+    auto load_log = [&]() {  // lane i <- step i of the phase (valid for lanes < nph)
+        const scan_u32x2 e = *(lds_u32x2 *)(log_off + (uint32_t)lane * 8u);
+        pos_log = e.x - 1u;
+        dig_log = e.y;
+        slot_log = e.y & 1023u;
+        if (TRACE) pop_log = popq[lane];
+    };
     auto refill_tick = [&](uint32_t lo, uint32_t hi) {
+        load_log();
         if (rq_state == 2) {  // C: land
             const uint2 mm = meta[rq_slot];
             const uint32_t wbase = rq_slot * W;
@@ -274,6 +288,7 @@ __global__ void __launch_bounds__(256, 4)
         }
     };
     auto flush = [&]() {
+        load_log();
         // ---- uses first: everything consumed here was requested at least one phase ago ----
         {   // R3: in-order discounted-return accumulation (psrs.py:262-269).  The sums must be sequential (bit-exact Gs),
             // so the inner loop is just two v_readlane and one v_add_f64 per step; episode ends (about one per phase)
@@ -364,75 +379,76 @@ __global__ void __launch_bounds__(256, 4)
             m = meta[slot];
             kt = ring[(c + lane) & (OFFSIM_RING - 1)];
         }
-        // fast loop: one iteration = one accepted step served from the LDS window.  Single exit (`go`), so that the
-        // back edge is one scalar branch; why it stopped is read from (ok, many) afterwards.
-        uint32_t last_dig = 0;
-        uint64_t many = 0, macc = 0;
-        uint32_t stop;  // 0 = keep going
-        // the current state also lives in a VGPR inside the loop: its address arithmetic then runs on the VALU instead
-        // of the one scalar ALU that the CU's 16 rollouts share (the loop was scalar-issue bound)
-        uint32_t vslot;
+        // fast loop: one iteration = one accepted step served from the LDS window.  The four wavefronts of a SIMD share
+        // its issue port and the sixteen of a CU its scalar unit, and the kernel time follows the NUMBER of instructions in
+        // this loop, vector or scalar alike (measured: 47 -> 41 -> 45 instructions gave 1.90 -> 1.74 -> 1.88 s).  So: the
+        // ring holds the draws pre-shifted (k21 << 11), which lets one compare against the whole digest find the first lane
+        // that is not a clear reject; only that lane's tie test is done, on the scalar side; per-state addresses are kept in
+        // vector registers; the step log is one LDS store; each kind of event has its own rarely taken exit.
+        uint64_t many = 0;
+        bool accepted;  // the last look accepted a candidate (the loop was left for an event)
+        uint32_t vslot, vlog;
         asm("v_mov_b32 %0, %1" : "=v"(vslot) : "s"(slot));
+        asm("v_mov_b32 %0, %1" : "=v"(vlog) : "s"(log_off + nph * 8u));  // LDS address of the log entry of the next step
         uint32_t vrow = win_off + vslot * (uint32_t)(W * 4), vmeta = meta_off + vslot * 8u;  // LDS addresses of its window row and meta entry
-        int vrel = lane - (int)nph;                       // lane - (steps logged this phase): the lane with 0 logs the next step
+        uint32_t v1023, vringm;
+        asm("v_mov_b32 %0, 0x3ff" : "=v"(v1023));
+        asm("v_mov_b32 %0, %1" : "=v"(vringm) : "s"(OFFSIM_RING * 4u - 4u));
+        uint32_t *plog = popq + nph;
         const uint32_t nph_in = nph;
         int tick_b = (int)((TICK - 1u) - (nph & (TICK - 1u)));  // goes negative when a multiple of TICK steps has been logged
         const int b_in = tick_b;
         const uint32_t gen_m64 = gen - 64u;
-        do {
-            const uint32_t v_avail = m.y - m.x;  // 0 = dry window: then no lane is valid and the loop stops as "all rejected"
-            const uint32_t v_nv = v_avail < (uint32_t)W ? v_avail : (uint32_t)W;
-            // candidate `lane` of the current state sits at ring position (cur + lane) mod W of its row (lanes >= W read
-            // some entry of the row and are masked below)
+        for (;;) {
+            // candidate `lane` of the current state sits at ring position (cur + lane) mod W of its row; entries that have
+            // not landed (and lanes >= W) get an empty digest: they never win, kt <= 0 only as a tie
+            const uint32_t v_avail = m.y - m.x;
             uint32_t dig = *(lds_u32 *)((((m.x + (uint32_t)lane) << 2) & (uint32_t)(W * 4 - 4)) | vrow);
-            dig = (uint32_t)lane < v_nv ? dig : 0u;  // lanes beyond the window never win (kt <= 0 only as a tie)
-            const uint32_t Tt = dig >> 11;
-            many = __ballot(kt <= Tt);
-            macc = __ballot(kt < Tt);
-            // f = first lane that is not a clear reject (s_ff1 gives -1 when there is none: the shift then reads bit 63 of
-            // macc, which is always 0 because lanes >= W carry an empty digest); ok = that lane is a clear accept
+            dig = (uint32_t)lane < (v_avail < (uint32_t)W ? v_avail : (uint32_t)W) ? dig : 0u;
+            many = __ballot(kt <= dig);  // not a clear reject: k21 <= T21 (the low 11 bits of kt are zero)
             int f;
-            asm("s_ff1_i32_b64 %0, %1" : "=s"(f) : "s"(many));
-            stop = 1u;
-            if (__builtin_expect(((macc >> (f & 63)) & 1ull) != 0ull, 1)) {
-                const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
-                const uint32_t v_pos = m.x + (uint32_t)f;
-                *(lds_u32 *)vmeta = v_pos + 1u;  // meta[vslot].x
-                const bool mine = vrel == 0;
-                vrel -= 1;
-                uint32_t vdig;
-                asm("v_mov_b32 %0, %1" : "=v"(vdig) : "s"(acc_dig));
-                pos_log = mine ? v_pos : pos_log;
-                slot_log = mine ? vslot : slot_log;
-                dig_log = mine ? vdig : dig_log;          // its bit 10 is the episode-end flag of the step
-                c += (uint32_t)f + 1u;
-                if (TRACE) {
-                    pop_log = mine ? pop_acc + (uint32_t)f + 1u : pop_log;
-                    pop_acc = 0;
-                }
-                tick_b -= 1;
-                vslot = vdig & 1023u;
-                vrow = win_off + vslot * (uint32_t)(W * 4);
-                vmeta = meta_off + vslot * 8u;
-                kt = *(lds_u32 *)((((c + (uint32_t)lane) << 2) & (OFFSIM_RING * 4 - 4)) | ring_off);  // fetched one step ahead: needs only the new draw count
-                {
-                    const scan_u32x2 mv = *(lds_u32x2 *)vmeta;  // and the next state
-                    m.x = mv.x;
-                    m.y = mv.y;
-                }
-                last_dig = acc_dig;
-                // one scalar test for the rare events: episode end | a multiple of 32 steps logged | fewer than 64 draws left
-                stop = ((acc_dig >> 10) & 1u) | (((uint32_t)tick_b | (gen_m64 - c)) >> 31);
+            asm("s_ff1_i32_b64 %0, %1" : "=s"(f) : "s"(many));  // -1 if none: lane 63 is read below, its digest is empty
+            const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)dig, f);
+            const uint32_t acc_kt = (uint32_t)__builtin_amdgcn_readlane((int)kt, f);
+            accepted = acc_kt < (acc_dig & 0xfffff800u);  // clear accept: k21 < T21
+            if (__builtin_expect(!accepted, 0)) break;
+            const uint32_t f1 = (uint32_t)f + 1u;
+            const uint32_t cur1 = m.x + f1;
+            *(lds_u32 *)vmeta = cur1;  // meta[vslot].x
+            {
+                scan_u32x2 e;
+                e.x = cur1;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(e.y) : "v"(v1023), "v"(vslot), "s"(acc_dig));  // digest with z_next replaced by the state left
+                *(lds_u32x2 *)vlog = e;
+                vlog += 8u;
             }
-        } while (__builtin_expect(stop == 0u, 1));
+            c += f1;
+            if (TRACE) {
+                *plog++ = pop_acc + f1;
+                pop_acc = 0;
+            }
+            tick_b -= 1;
+            asm("v_bfe_u32 %0, %1, 0, 10" : "=v"(vslot) : "s"(acc_dig));  // next state
+            vrow = win_off + vslot * (uint32_t)(W * 4);
+            vmeta = meta_off + vslot * 8u;
+            {
+                uint32_t ka = (c + (uint32_t)lane) << 2;
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ka) : "v"(ka), "v"(vringm), "s"(ring_off));
+                kt = *(lds_u32 *)ka;  // fetched one step ahead: needs only the new draw count
+            }
+            {
+                const scan_u32x2 mv = *(lds_u32x2 *)vmeta;  // and the next state
+                m.x = mv.x;
+                m.y = mv.y;
+            }
+            dn = (acc_dig >> 10) & 1u;
+            if (__builtin_expect(dn, 0)) break;                                             // episode end
+            if (__builtin_expect((int)((uint32_t)tick_b | (gen_m64 - c)) < 0, 0)) break;  // a multiple of 32 steps logged | fewer than 64 draws left
+        }
         slot = (int)__builtin_amdgcn_readfirstlane(vslot);
         nph = nph_in + (uint32_t)(b_in - tick_b);
-        int f_last;
-        asm("s_ff1_i32_b64 %0, %1" : "=s"(f_last) : "s"(many));
-        if (((macc >> (f_last & 63)) & 1ull) != 0ull) {  // the last look accepted: left for a rare event
-            dn = (last_dig >> 10) & 1u;
-            goto ev_tail;
-        }
+        if (accepted) goto ev_tail;  // left for a rare event (dn says whether the episode ended)
+        dn = false;
         if (many == 0ull) {
             if (__builtin_amdgcn_readfirstlane(m.y - m.x) != 0u) {  // every window candidate rejected: consume them, look again
                 const uint32_t v_avail = m.y - m.x;
@@ -467,7 +483,8 @@ __global__ void __launch_bounds__(256, 4)
             const uint32_t g = perm_row ? perm_row[p] : p;
             const uint64_t key = keys[g];
             const uint32_t Tt = (uint32_t)(key >> 43);
-            uint64_t macc = __ballot(valid && kt < Tt), mamb = __ballot(valid && kt == Tt);
+            const uint32_t k21 = kt >> 11;
+            uint64_t macc = __ballot(valid && k21 < Tt), mamb = __ballot(valid && k21 == Tt);
             int f = -1;
             while (true) {
                 const uint64_t mm = macc | mamb;
@@ -496,14 +513,16 @@ __global__ void __launch_bounds__(256, 4)
             if (TRACE) pop_acc += d;
             if (f >= 0) {
                 const uint32_t acc_dig = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), f);
-                const bool mine = (uint32_t)lane == nph;
-                pos_log = mine ? cur_z + (uint32_t)f : pos_log;
-                slot_log = mine ? (uint32_t)slot : slot_log;
+                {
+                    scan_u32x2 e;
+                    e.x = cur_z + (uint32_t)f + 1u;
+                    e.y = (acc_dig & ~1023u) | (uint32_t)slot;
+                    *(lds_u32x2 *)(log_off + nph * 8u) = e;
+                }
                 if (TRACE) {
-                    pop_log = mine ? pop_acc : pop_log;
+                    popq[nph] = pop_acc;
                     pop_acc = 0;
                 }
-                dig_log = mine ? acc_dig : dig_log;
                 dn = (acc_dig >> 10) & 1u;
                 nph++;
                 slot = (int)(acc_dig & 1023u);
