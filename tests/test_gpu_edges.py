@@ -119,3 +119,38 @@ def test_shared_and_table_order_modes_agree_between_kernels(gpu):
         torch.cuda.synchronize()
         for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status", "trace_row", "trace_pop"):
             assert torch.equal(outs[0][k], outs[1][k]), (mode, k)
+
+
+@pytest.mark.parametrize("N,nS,p_t0,skew", [
+    (64, 1, 1.0, False),          # one group of exactly 64 steps is never full: the partial-group path
+    (1000, 7, None, False),       # small segments, several chains per compute unit
+    (70000, 1, 1.0, False),       # one state of 70000 rows and an init queue of 70000: the in-place global-memory variant
+    (131072, 2, 0.5, False),      # segments around the 65536-row LDS capacity, init queue just below it
+    (300000, 40, None, True),     # a 210000-row state next to tiny ones
+])
+def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
+    """offsim_shuffle_queues (shuffle_wave.hpp: wave-parallel Fisher-Yates) against the oracle's restatement of
+    default_rng(seed).shuffle per queue (psrs.py:22-23, 29-30), for both memory variants and the rare paths
+    (mask boundaries, settled accepts, arithmetic cuts, equal partners, partial last group)."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable, seeds_tensor, shuffle_queues
+    e = synth.synth_iid(N, nS, 2, seed=N + nS)
+    if skew:
+        rng = np.random.default_rng(5)
+        e["z"] = np.where(rng.random(N) < 0.7, 0, rng.integers(0, nS, N)).astype(e["z"].dtype)
+    t0 = e["steps"] == 0 if p_t0 is None else np.random.default_rng(3).random(N) < p_t0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    seeds = [0, 7, 2 ** 40 + 3]
+    perm, init_perm = shuffle_queues(table, seeds_tensor(np.asarray(seeds, dtype=np.uint64), gpu))
+    torch.cuda.synchronize()
+    perm = perm.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    init_perm = init_perm.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    so = table.seg_off.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    for k, seed in enumerate(seeds):
+        for s in range(table.n_slots):
+            n = int(so[s + 1] - so[s])
+            if n:
+                assert np.array_equal(perm[k, so[s]:so[s + 1]], so[s] + O.permutation(seed, n)), (seed, s, n)
+        if table.N0:
+            assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
