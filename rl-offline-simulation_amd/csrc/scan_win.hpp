@@ -300,6 +300,12 @@ __global__ void __launch_bounds__(256, 4)
                 const uint32_t e = dm ? (uint32_t)__ffsll((unsigned long long)dm) - 1u : n2;  // next episode end (index) or none
                 const uint32_t run_end = e < n2 ? e + 1u : n2;
                 len_acc += run_end - i;
+                for (; i + 4u <= run_end; i += 4u) {  // (unrolled: the loop control costs as much as the additions)
+                    G = G + readlane_f64(prod, (int)i);
+                    G = G + readlane_f64(prod, (int)i + 1);
+                    G = G + readlane_f64(prod, (int)i + 2);
+                    G = G + readlane_f64(prod, (int)i + 3);
+                }
                 for (; i < run_end; i++) G = G + readlane_f64(prod, (int)i);
                 if (e < n2) {
                     if (lane == 0) {
