@@ -5,5 +5,5 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I../../include \
  -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
- -Wall -Wno-unused-function"
+ -Wall -Wno-unused-function -Wno-int-to-pointer-cast"
 $HIPCC $FLAGS "$@" -o liboffsim_hip.so offsim_hip.hip
