@@ -74,6 +74,8 @@ typedef struct offsim_table {
     const int32_t *init_orig; /* [N0]   its row in the caller's buffer                          */
     int64_t max_seg;          /* longest state segment (max of seg_off[s+1]-seg_off[s]); 0 = unknown:
                                  the shuffle then sizes its LDS for the worst case (65536 rows)      */
+    int64_t min_seg;          /* shortest non-empty state segment; 0 = unknown (the shuffle then launches
+                                 every size class)                                                  */
 } offsim_table;
 
 /* State of R independent simulated rollouts (one PSRS env each).  Owned by the caller. */

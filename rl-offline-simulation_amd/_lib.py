@@ -22,7 +22,7 @@ class Table(C.Structure):
     """struct offsim_table"""
     _fields_ = [("N", _i64), ("n_slots", _i32), ("nA", _i32), ("plog_dtype", _i32), ("r_dtype", _i32),
                 ("seg_off", _vp), ("p_log", _vp), ("a", _vp), ("r", _vp), ("z_next", _vp), ("done", _vp),
-                ("orig_idx", _vp), ("N0", _i64), ("init_slot", _vp), ("init_orig", _vp), ("max_seg", _i64)]
+                ("orig_idx", _vp), ("N0", _i64), ("init_slot", _vp), ("init_orig", _vp), ("max_seg", _i64), ("min_seg", _i64)]
 
 
 class Rollouts(C.Structure):

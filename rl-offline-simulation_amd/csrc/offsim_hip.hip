@@ -332,11 +332,8 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
     if (!legacy) {
         // wave-parallel exact Fisher-Yates (shuffle_wave.hpp): one workgroup per chain
         const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
-        const uint32_t max_small = max_seg < SHUF_CAP16 ? max_seg : SHUF_CAP16;  // longest state segment that can live in LDS
-        uint32_t need16 = max_small;
-        if (t->N0 <= (int64_t)SHUF_CAP16 && (uint32_t)t->N0 > need16) need16 = (uint32_t)t->N0;
-        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need16 * 2 + 15) & ~(size_t)15) + 16;
-        const size_t lds32 = shuf_fixed_lds_bytes();
+        const uint32_t min_seg = t->min_seg > 0 ? (uint32_t)(t->min_seg > 0xffffffffll ? 0xffffffffll : t->min_seg) : 1u;
+        const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
         const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
         if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
         static bool attr_set = false;
@@ -345,15 +342,26 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
             attr_set = true;
         }
         static const int dbg_mode = getenv("OFFSIM_SHUFFLE_DBG") ? atoi(getenv("OFFSIM_SHUFFLE_DBG")) : 0;  // stage timing experiments (results are wrong)
-        const bool any_big = max_seg > SHUF_CAP16 || t->N0 > (int64_t)SHUF_CAP16;
-        if (any_big) {  // first: these chains are the long ones
-            hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), lds32, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
-                               n_perm, perm_out, init_perm_out, SHUF_CAP16, dbg_mode);
+        if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
+            hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(), st, t->seg_off, t->n_slots, t->N,
+                               t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dbg_mode);
             LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds, n_perm,
-                           perm_out, init_perm_out, SHUF_CAP16, dbg_mode);
-        LAUNCH_CHECK();
+        // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
+        // chains share a CU instead of inheriting the one-chain-per-CU occupancy of a 60 k-row segment
+        static const uint32_t bounds[] = {SHUF_CAP16, 32768u, 8192u, 2048u, 0u};
+        for (int k = 0; k < 4; k++) {
+            const uint32_t hi = bounds[k], lo = bounds[k + 1];
+            const bool seg_in = min_seg <= hi && max_seg > lo, init_in = n0 > lo && n0 <= hi;
+            if (!seg_in && !init_in) continue;
+            uint32_t need = 0;
+            if (seg_in) need = max_seg < hi ? max_seg : hi;
+            if (init_in && n0 > need) need = n0;
+            const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
+            hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
+                               n_perm, perm_out, init_perm_out, lo, hi, dbg_mode);
+            LAUNCH_CHECK();
+        }
         return OFFSIM_OK;
     }
     // start from table order: perm[r][g] = g, init_perm[r][k] = k

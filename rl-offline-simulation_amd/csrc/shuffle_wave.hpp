@@ -53,12 +53,13 @@ __device__ __forceinline__ int sh_rank(uint64_t m) {  // set bits of m in front 
 // LDS layout: [ctrl 16 w][draw ring RG w][j ring SQ w + 64 w trash][64 w tag winners][segment]
 constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_SQ + 64u + 64u); }
 
-// LDS16 = true : segments with 1 <= n <= cap16 rows, kept in LDS as 16-bit local indices
-// LDS16 = false: segments with n > cap16 rows, shuffled in place in global memory (32-bit)
+// LDS16 = true : segments of n_lo < n <= n_hi <= 65536 rows, kept in LDS as 16-bit local indices (one launch per size class,
+//                so that short chains are not held to the occupancy of the longest)
+// LDS16 = false: segments with n > n_lo rows, shuffled in place in global memory (32-bit)
 template <bool LDS16>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
-                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t cap16, int dbg_mode) {
+                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi, int dbg_mode) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256)
         base_val = 0;
     }
     if (n == 0) return;
-    if (LDS16 ? (n > cap16) : (n <= cap16)) return;
+    if (n <= n_lo || (LDS16 && n > n_hi)) return;  // this launch serves the chains with n_lo < n <= n_hi (its LDS is sized for n_hi)
     volatile uint32_t *x32 = (volatile uint32_t *)xg;
 
     if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0;

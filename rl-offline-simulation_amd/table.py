@@ -105,12 +105,14 @@ class TransitionTable:
         self.init_slot = gather_rows(slot, init_rows)
         self._slot = slot
         so = self.seg_off.to(torch.int64) & 0xFFFFFFFF
-        self.max_seg = int((so[1:] - so[:-1]).max().item()) if N else 0
+        lens = so[1:] - so[:-1]
+        self.max_seg = int(lens.max().item()) if N else 0
+        self.min_seg = int(lens[lens > 0].min().item()) if N else 0
         self.c = L.Table(N=N, n_slots=self.n_slots, nA=self.nA, plog_dtype=_TAG_OF[self.p_log.dtype],
                          r_dtype=_TAG_OF[self.r.dtype], seg_off=L.ptr(self.seg_off), p_log=L.ptr(self.p_log),
                          a=L.ptr(self.a), r=L.ptr(self.r), z_next=L.ptr(self.z_next), done=L.ptr(self.done),
                          orig_idx=L.ptr(self.order), N0=self.N0, init_slot=L.ptr(self.init_slot),
-                         init_orig=L.ptr(self.init_orig), max_seg=self.max_seg)
+                         init_orig=L.ptr(self.init_orig), max_seg=self.max_seg, min_seg=self.min_seg)
 
     # ---- bookkeeping used by the measurement code ----
     @property

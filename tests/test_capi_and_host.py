@@ -44,7 +44,7 @@ def test_library_loads_without_gpu_and_reports_errors():
 
 def test_struct_layout_matches_header():
     from rl_offline_simulation_amd import _lib
-    assert ctypes.sizeof(_lib.Table) == 8 + 4 * 4 + 7 * 8 + 8 + 2 * 8 + 8  # ... + max_seg
+    assert ctypes.sizeof(_lib.Table) == 8 + 4 * 4 + 7 * 8 + 8 + 2 * 8 + 2 * 8  # ... + max_seg, min_seg
     assert ctypes.sizeof(_lib.Rollouts) == 8 + 4 * 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.EvalMCOut) == 13 * 8
 
