@@ -31,8 +31,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--transitions", type=int, default=10_000_000, help="logged transitions per GPU")
     ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts) per GPU")
-    ap.add_argument("--workload", default="iid", choices=["iid", "cartpole"],
-                    help="iid = S-iid synthetic log (headline); cartpole = CartPole dynamics + device box encoder (config C2)")
+    ap.add_argument("--workload", default="iid", choices=["iid", "cartpole", "grid"],
+                    help="iid = S-iid synthetic log (headline); cartpole = CartPole dynamics + device box encoder (config C2); "
+                         "grid = continuous_grid log + 2-64-25 MLP encoder forward on MFMA, random-init weights (config C3)")
     ap.add_argument("--n-states", type=int, default=162)
     ap.add_argument("--n-actions", type=int, default=2)
     ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
@@ -142,6 +143,18 @@ def main():
         enc = CartpoleBoxEncoder()
         e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
         a.n_states, a.n_actions = 162, 2
+    elif a.workload == "grid":
+        from rl_offline_simulation_amd.encoders import HOMEREncoder
+        e = synth.grid_coords_log_fast(N, seed=20221107 + rank)
+        g = torch.Generator().manual_seed(0)  # nn.Linear's default init, fixed seed (no trained checkpoint travels)
+        lin = lambda o, i: ((torch.rand((o, i), generator=g) * 2 - 1) / i ** 0.5, (torch.rand(o, generator=g) * 2 - 1) / i ** 0.5)
+        (W1, b1), (W2, b2) = lin(64, 2), lin(25, 64)
+        enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
+                                                      "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2}, device=dev)
+        t_e = time.perf_counter()
+        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+        encode_s = time.perf_counter() - t_e
+        a.n_states, a.n_actions = 25, 5
     else:
         e = synth.synth_iid(N, a.n_states, a.n_actions, seed=20221107 + rank)
     pi = synth.dirichlet_policy(a.n_states, a.n_actions)
@@ -221,7 +234,8 @@ def main():
             "value": value, "unit": "simulated steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"CartPole-dynamics log, uniform logger, device box encoder (C2), {N} transitions" if a.workload == "cartpole" else f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
+            "config": {"workload": (f"CartPole-dynamics log, uniform logger, device box encoder (C2), {N} transitions" if a.workload == "cartpole" else
+                                   f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA with random-init weights (C3), {N} transitions, host-to-z encode {encode_s:.2f} s" if a.workload == "grid" else f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
                                    f"evalMC_psrs to exhaustion, gamma={a.gamma}"), "transitions_per_gpu": N, "rollouts": R,
                        "shuffle": a.shuffle, "rollout_tile": tile, "p_log": "f32", "sharding": f"log sharded by episode over {world} GPU(s), "
                        "all seeds on every shard, RCCL all-reduce of per-seed (sum G, n episodes)"},
