@@ -336,15 +336,10 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
         const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
         const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
         if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_shuffle_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        static const int dbg_mode = getenv("OFFSIM_SHUFFLE_DBG") ? atoi(getenv("OFFSIM_SHUFFLE_DBG")) : 0;  // stage timing experiments (results are wrong)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_shuffle_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // (per device)
         if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
             hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(), st, t->seg_off, t->n_slots, t->N,
-                               t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dbg_mode);
+                               t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu);
             LAUNCH_CHECK();
         }
         // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
@@ -359,7 +354,7 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
             if (init_in && n0 > need) need = n0;
             const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
             hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
-                               n_perm, perm_out, init_perm_out, lo, hi, dbg_mode);
+                               n_perm, perm_out, init_perm_out, lo, hi);
             LAUNCH_CHECK();
         }
         return OFFSIM_OK;

@@ -59,7 +59,7 @@ constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_SQ
 template <bool LDS16>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
-                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi, int dbg_mode) {
+                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(256)
                 const uint32_t i_first = i_top;
                 const uint32_t il = i_first - (uint32_t)lane;
                 i_top -= 64u;
-                if (dbg_mode == 1) continue;
                 // a partner inside the group's own later steps: cut in front of the lane that owns that step
                 const uint64_t confl = __ballot(v < il) & __ballot(v > i_top);
                 const uint32_t a = xrd(il), b = xrd(v);
@@ -298,16 +297,14 @@ __global__ void __launch_bounds__(256)
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 const uint32_t il = i_top - (uint32_t)lane;
                 const bool in = (uint32_t)lane < cnt;
-                if (dbg_mode != 1) {
-                    const uint64_t confl = __ballot(in && v < il && v >= 1u);
-                    uint32_t b = 0, tg = (uint32_t)lane;
-                    if (in) {
-                        b = xrd(v);
-                        xwr(v, (uint32_t)lane);
-                        tg = xrd(v);
-                    }
-                    piecewise(cnt, i_top, il, v, b, tg, confl, __ballot(tg != (uint32_t)lane));
+                const uint64_t confl = __ballot(in && v < il && v >= 1u);
+                uint32_t b = 0, tg = (uint32_t)lane;
+                if (in) {
+                    b = xrd(v);
+                    xwr(v, (uint32_t)lane);
+                    tg = xrd(v);
                 }
+                piecewise(cnt, i_top, il, v, b, tg, confl, __ballot(tg != (uint32_t)lane));
             }
         }
     }
