@@ -94,8 +94,9 @@ class BatchedPSRS:
         return self._row, self._status, self._popped
 
     def step_single(self, p_new, advance=True, reject_mode=None):
-        """R = 1 convenience for the drop-in classes: one H2D copy, one launch, one D2H copy through pinned buffers.
-        Returns host ints (row, status, popped)."""
+        """R = 1 convenience for the drop-in classes: one launch per call.  The kernel reads p_new from, and writes
+        (row, status, popped) to, pinned host memory mapped into the device's address space, so that no copy is enqueued:
+        the call is launch + stream synchronise.  Returns host ints (row, status, popped)."""
         t = self.table
         p_new = np.asarray(p_new)
         mode = _prob_mode(t, p_new.dtype)
@@ -103,19 +104,16 @@ class BatchedPSRS:
         if getattr(self, "_single_key", None) != key:
             dt = torch.float32 if mode == L.PROB_F32 else torch.float64
             self._p_host = torch.empty((1, t.nA), dtype=dt).pin_memory()
-            self._p_dev = torch.empty((1, t.nA), dtype=dt, device=t.device)
-            self._o_dev = torch.empty(3, dtype=torch.int32, device=t.device)
             self._o_host = torch.empty(3, dtype=torch.int32).pin_memory()
+            self._p_np, self._o_np = self._p_host.numpy(), self._o_host.numpy()
             self._single_key = key
-        self._p_host.copy_(torch.from_numpy(np.ascontiguousarray(p_new.reshape(1, -1))))
-        self._p_dev.copy_(self._p_host, non_blocking=True)
+        self._p_np[0, :] = p_new.reshape(-1)
         rm = self.reject_mode if reject_mode is None else reject_mode
-        base = self._o_dev.data_ptr()
-        L.check(L.load().offsim_step_batch(C.byref(t.c), C.byref(self.state.c), L.ptr(self._p_dev), mode, rm, 1 if advance else 0,
+        base = self._o_host.data_ptr()
+        L.check(L.load().offsim_step_batch(C.byref(t.c), C.byref(self.state.c), self._p_host.data_ptr(), mode, rm, 1 if advance else 0,
                                            base, base + 4, base + 8, L.stream_ptr()))
-        self._o_host.copy_(self._o_dev, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        row, status, popped = self._o_host.tolist()
+        row, status, popped = int(self._o_np[0]), int(self._o_np[1]), int(self._o_np[2])
         self.last_row = row
         return row, status, popped
 
