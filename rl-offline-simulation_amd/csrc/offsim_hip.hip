@@ -984,6 +984,7 @@ extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const 
 // Fast evalMC scan: compiled-policy keys + LDS candidate windows (scan_win.hpp)
 // ------------------------------------------------------------------------------------------------
 #include "scan_win.hpp"
+#include "scan_split.hpp"
 
 extern "C" int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream) {
     int rc = check_table(t);
@@ -1029,6 +1030,32 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
                                n_gamma_pow, max_episodes, *out);                                                      \
     } while (0)
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
+    static const bool split = getenv("OFFSIM_SCAN_SPLIT") != nullptr;  // chain wave + helper wave per rollout (scan_split.hpp)
+    if (split) {
+#define LAUNCH_SPLIT(W, ROUNDS)                                                                                       \
+    do {                                                                                                              \
+        const size_t region = (OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 +             \
+                               (trace ? split_log_bytes<W, true>() : split_log_bytes<W, false>()) + 511) & ~(size_t)511; \
+        const size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) + 4 * region;                   \
+        dim3 grid2((ro->R + 3) / 4), block2(512);                                                                     \
+        if (trace) {                                                                                                  \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc_split<W, ROUNDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, true>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+        } else {                                                                                                      \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc_split<W, ROUNDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, false>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+        }                                                                                                             \
+    } while (0)
+        if (rounds == 1) LAUNCH_SPLIT(32, 1);
+        else if (rounds == 2) LAUNCH_SPLIT(8, 2);
+        else if (rounds == 3) LAUNCH_SPLIT(8, 3);
+        else LAUNCH_SPLIT(8, 4);
+#undef LAUNCH_SPLIT
+        LAUNCH_CHECK();
+        return OFFSIM_OK;
+    }
     if (rounds == 1) LAUNCH_WIN(32, 1);
     else if (rounds == 2) LAUNCH_WIN(8, 2);
     else if (rounds == 3) LAUNCH_WIN(8, 3);
