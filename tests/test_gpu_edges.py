@@ -156,12 +156,14 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
             assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
 
 
-def test_split_scan_variant_passes_the_same_parity_suite(gpu):
-    """csrc/scan_split.hpp (chain wave + helper wave per rollout) is opt-in through OFFSIM_SCAN_SPLIT, which the library
-    reads once per process: run the golden-fixture parity tests again in a child process with it set."""
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_both_scan_variants_pass_the_parity_suite(variant, gpu):
+    """The library picks csrc/scan_split.hpp (chain wave + helper wave per rollout) for <= 3072 rollouts and the
+    monolithic csrc/scan_win.hpp above; OFFSIM_SCAN_SPLIT=0/1 forces one of them and is read once per process: run the
+    golden-fixture parity tests in a child process with each."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, OFFSIM_SCAN_SPLIT="1")
+    env = dict(os.environ, OFFSIM_SCAN_SPLIT=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
