@@ -2,18 +2,28 @@
 """Headline benchmark: simulated steps/sec (node), 10 M logged transitions x 4096 rollouts.
 
 One "step" = one full pass of the hot path over the batch of rollouts on every rank:
-  PSRS.reset_sampler(seed_r) for all R seeds   (offsim_seed_streams + offsim_shuffle_queues)
-  evalMC_psrs until the buffer is exhausted     (offsim_eval_mc)
+  PSRS.reset_sampler(seed_r) for all R seeds   (offsim_seed_streams + offsim_shuffle_queues[_keys])
+  evalMC_psrs until the buffer is exhausted     (offsim_eval_mc[_keys])
+  one all-reduce of the per-seed (sum G, n episodes) pairs when there is more than one rank
 with the logged-transition table already resident in HBM.  value = accepted steps of all rollouts on all
-ranks / wall time (max over ranks).  Multi-GPU = weak scaling: every rank owns its own 10 M-transition shard
-of the log (shards are episode-disjoint), runs all R seeds on it, and the per-seed (sum G, n episodes) pairs
-are combined with one RCCL all-reduce.
+ranks / wall time (max over ranks).
 
-Prints ONE JSON line on rank 0; see README/DESIGN.md for the fields `roofline` and `cpu_baseline`.
+Multi-GPU (`--gpus N`): one process per GPU.  When the ranks do not exist yet (no WORLD_SIZE in the environment)
+this script starts them itself -- N child processes with RANK / LOCAL_RANK / WORLD_SIZE set, before anything in
+this process has touched the GPU -- otherwise (torchrun / torch.distributed.run) it is one of the ranks.
+  --scaling strong (default): the SAME 10 M-transition log at every N, split into N episode-disjoint shards, all R
+      seeds on every shard, one RCCL all-reduce of [R,2] f64 (second axis).  Also measured and reported as
+      the extra field `rollout_sharded`: table replicated, R/N seeds per GPU (primary axis).
+  --scaling weak: every rank owns its own 10 M-transition log (N x 10 M in total), all R seeds on each.
+
+Prints ONE JSON line on rank 0; see DESIGN.md section 5 for `roofline`, `cpu_baseline`, `parity_check`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,101 +33,239 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PARITY_SEEDS = (0, 1, 2047, 4095)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--transitions", type=int, default=10_000_000, help="logged transitions per GPU")
-    ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts) per GPU")
+    ap.add_argument("--transitions", type=int, default=10_000_000, help="logged transitions (whole job with --scaling strong, per GPU with weak)")
+    ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--no-rollout-sharded", action="store_true", help="skip the extra rollout-sharded measurement of a strong multi-GPU run")
     ap.add_argument("--workload", default="iid", choices=["iid", "cartpole", "grid"],
                     help="iid = S-iid synthetic log (headline); cartpole = CartPole dynamics + device box encoder (config C2); "
                          "grid = continuous_grid log + 2-64-25 MLP encoder forward on MFMA, random-init weights (config C3)")
     ap.add_argument("--n-states", type=int, default=162)
     ap.add_argument("--n-actions", type=int, default=2)
     ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
-    ap.add_argument("--tile", type=int, default=4096, help="rollouts whose queue permutations are resident at once")
+    ap.add_argument("--tile", type=int, default=4096, help="rollouts whose queue orders are resident at once")
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="plumbing test: several ranks share GPU 0 (use with --dist-backend gloo)")
-    ap.add_argument("--cpu-sample-transitions", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads-cap", type=int, default=64, help="host threads of the CPU baseline (each holds its own queues: 170 MB at 10 M rows)")
+    ap.add_argument("--print-csrc-digest", action="store_true", help="print the digest of the kernel sources (recorded by tools/profile_bench.sh) and exit")
     return ap.parse_args()
 
 
-def cpu_baseline(e, pi, gamma, n_sample, budget_s):
-    """The oracle (C port of the reference loop) on a bounded sample of the same workload, on all host cores: rollouts
-    are independent, so each thread owns one oracle object and runs whole rollouts (ctypes releases the GIL)."""
-    import threading
+def csrc_digest():
+    """Digest of everything that is compiled into liboffsim_hip.so: ties a committed rocprofv3 profile to the kernels it measured."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rl-offline-simulation_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/offsim.h"]:
+        if f.endswith((".hip", ".hpp", ".h", ".sh")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no ranks around yet
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(a):
+    """Starts a.gpus copies of this command, one per GPU, and waits for them.  Nothing here touches the GPU (children are
+    started with subprocess from a process that never initialised HIP), rank 0's stdout is this process's stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(a.gpus))
+        while pending:
+            for r in list(pending):
+                c = procs[r].poll()
+                if c is not None:
+                    pending.discard(r)
+                    if c != 0:
+                        rc = rc or c
+                        for q in pending:  # one rank failed: the others would wait in a collective forever
+                            procs[q].terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU legs (the oracle is the checker and the reported baseline; never the product path)
+# ---------------------------------------------------------------------------------------------------
+def oracle_for(e):
     from oracle import oracle as O
-    sl = slice(0, n_sample)
-    t0 = e["steps"][sl] == 0
-    cols = (e["z"][sl], e["actions"][sl], e["rewards"][sl], e["z_next"][sl], e["terminals"][sl], e["action_distributions"][sl], t0)
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     O.lib()
-    steps = [0] * cores
-    rolls = [0] * cores
+    return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+
+
+def parity_check(base, pi, gamma, seeds, got):
+    """The oracle on a few seeds of the SAME table the timed passes ran on (one rollout per host thread), against what the
+    GPU returned for those seeds: accepted steps, candidates examined and completed episodes equal, value estimate
+    within 1e-5 (BASELINE.json north_star)."""
+    import threading
+    res = [None] * len(seeds)
+
+    def work(k):
+        o = base.clone()
+        o.reset_sampler(int(seeds[k]))
+        res[k] = o.evalmc(10 ** 9, pi, gamma)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(seeds))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    ok, worst = True, 0.0
+    rows = []
+    for k, s in enumerate(seeds):
+        ref = res[k]
+        n_ep = len(ref["Gs"])
+        v_ref = float(ref["Gs"].mean()) if n_ep else float("nan")
+        g = got[int(s)]
+        v = g["sum_g"] / g["n_ep"] if g["n_ep"] else float("nan")
+        err = abs(v - v_ref) if n_ep else 0.0
+        same = (g["steps"] == ref["steps"] and g["cand"] == ref["candidates"] and g["n_ep"] == n_ep and err <= 1e-5)
+        ok &= bool(same)
+        worst = max(worst, err)
+        rows.append({"seed": int(s), "steps": ref["steps"], "candidates": ref["candidates"], "episodes": n_ep, "value": v_ref, "match": bool(same)})
+    return {"seeds": [int(s) for s in seeds], "ok": bool(ok), "max_abs_value_err": worst, "tolerance": 1e-5, "table_rows": int(base.N),
+            "checked": "accepted steps, candidates examined, completed episodes equal; |sum_g/n_ep - mean(Gs)| <= 1e-5; oracle/psrs_oracle.c, "
+                       "one full rollout per seed on this rank's table", "oracle": rows}
+
+
+def cpu_baseline(base, pi, gamma, budget_s, cap):
+    """The oracle (C port of the reference loop) on the same table, bounded by time: whole rollouts (reset_sampler + evalMC
+    to exhaustion), first on one thread (the reference is single-threaded), then one rollout per host thread."""
+    import threading
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = min(cores, cap)
+    one = base.clone()
+    t0 = time.perf_counter()
+    s1 = r1 = 0
+    while True:
+        one.reset_sampler(r1)
+        s1 += one.evalmc(10 ** 9, pi, gamma)["steps"]
+        r1 += 1
+        if time.perf_counter() - t0 > budget_s / 3:
+            break
+    el1 = time.perf_counter() - t0
+    objs = [one] + [base.clone() for _ in range(cores - 1)]
+    steps, rolls = [0] * cores, [0] * cores
     t_start = time.perf_counter()
 
-    def work(k, stride=None):
-        ora = O.OraclePSRS(*cols)
-        seed = k
+    def work(k):
+        seed = 100 + k
         while True:
-            ora.reset_sampler(seed)
-            steps[k] += ora.evalmc(10 ** 9, pi, gamma)["steps"]
+            objs[k].reset_sampler(seed)
+            steps[k] += objs[k].evalmc(10 ** 9, pi, gamma)["steps"]
             rolls[k] += 1
-            seed += cores if stride is None else stride
-            if time.perf_counter() - t_start > budget_s or seed >= 4096:
+            seed += cores
+            if time.perf_counter() - t_start > budget_s * 2 / 3:
                 break
 
-    # one core first (the reference itself is single-threaded), then all of them
-    work(0, stride=1)
-    el1 = time.perf_counter() - t_start
-    v1, r1 = steps[0] / el1, rolls[0]
-    steps[0] = rolls[0] = 0
-    t_start = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
     for x in th:
         x.start()
     for x in th:
         x.join()
     el = time.perf_counter() - t_start
-    return {"value": sum(steps) / el, "unit": "simulated steps/s", "cores": cores, "kind": "port", "value_one_core": v1,
-            "sample": f"{sum(rolls)} rollouts (reset_sampler + evalMC to exhaustion) over the first {n_sample} transitions of the same "
-                      f"synthetic log, {el:.1f} s of oracle/psrs_oracle.c on {cores} host threads (one rollout per thread); "
+    return {"value": sum(steps) / el, "unit": "simulated steps/s", "cores": cores, "kind": "port", "value_one_core": s1 / el1,
+            "sample": f"{sum(rolls)} whole rollouts (reset_sampler + evalMC to exhaustion) over the SAME {base.N}-transition table as the "
+                      f"timed passes, {el:.1f} s of oracle/psrs_oracle.c on {cores} host threads (one rollout per thread); "
                       f"one thread alone: {r1} rollouts in {el1:.1f} s"}
 
 
-def pmc_traffic(a):
-    """Bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/, collected by tools/profile_bench.sh; PMC cannot be read from inside the run).  FETCH_SIZE/WRITE_SIZE
-    in KB; 4-byte random-sector gathers are counted 1:1 on this GPU (tools/calib_fetch.py), and the counters sit on
-    the fabric side of L2, i.e. they include Infinity-Cache hits: an upper bound of the HBM bytes."""
+def pmc_traffic(a, kernel, world):
+    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 --pmc passes committed under profiles/ (PMC cannot
+    be read from inside the run).  Used only when that profile was taken with the kernel sources of THIS build
+    (summary.json records their digest) and with this command; otherwise null."""
     default = (a.workload == "iid" and a.transitions == 10_000_000 and a.rollouts == 4096 and a.n_states == 162 and
-               a.n_actions == 2 and a.shuffle == "per_rollout")
-    path = os.path.join(ROOT, "profiles", "r01_rocprof_bench_10Mx4096", "summary.json")
-    if not default or not os.path.exists(path):
-        return None, None
-    try:
-        s = json.load(open(path))
-        calls = [int(r["Calls"]) for r in s["kernel_stats"] if "k_eval_mc_win" in r["Name"]][0]
-        kb = sum(v.get("FETCH_SIZE", 0.0) for k, v in s["pmc_fetch"].items() if "k_eval_mc_win" in k)
-        kb += sum(v.get("WRITE_SIZE", 0.0) for k, v in s["pmc_write"].items() if "k_eval_mc_win" in k)
-        return kb * 1024.0 / calls, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_rocprof_bench_10Mx4096), fabric-side: includes Infinity-Cache hits"
-    except Exception:
-        return None, None
+               a.n_actions == 2 and a.shuffle == "per_rollout" and world == 1)
+    if not default:
+        return None, "no PMC profile for this command"
+    dig = csrc_digest()
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        path = os.path.join(pdir, d, "summary.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            s = json.load(open(path))
+            if s.get("csrc_digest") != dig:
+                continue
+            calls = [int(r["Calls"]) for r in s["kernel_stats"] if kernel in r["Name"]][0]
+            kb = sum(v.get("FETCH_SIZE", 0.0) for k, v in s["pmc_fetch"].items() if kernel in k)
+            kb += sum(v.get("WRITE_SIZE", 0.0) for k, v in s["pmc_write"].items() if kernel in k)
+            return kb * 1024.0 * s.get("fetch_scale", 1.0) / calls, (
+                f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with these kernel sources (profiles/{d}, csrc digest {dig}); "
+                "fabric-side of L2: includes Infinity-Cache hits")
+        except Exception:
+            continue
+    return None, f"no committed PMC profile matches the kernel sources of this build (csrc digest {dig})"
 
 
-def main():
-    a = parse()
+# ---------------------------------------------------------------------------------------------------
+def make_log(a, seed, dev):
+    """The logged experience (host arrays, OfflineDataset schema + z / z_next) of this workload."""
+    import torch
+    from rl_offline_simulation_amd import synth
+    N = a.transitions
+    note = ""
+    if a.workload == "cartpole":
+        from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+        e = synth.cartpole_log(N, seed=seed)
+        enc = CartpoleBoxEncoder()
+        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+        a.n_states, a.n_actions = 162, 2
+    elif a.workload == "grid":
+        from rl_offline_simulation_amd.encoders import HOMEREncoder
+        e = synth.grid_coords_log_fast(N, seed=seed)
+        g = torch.Generator().manual_seed(0)  # nn.Linear's default init, fixed seed (no trained checkpoint travels)
+        lin = lambda o, i: ((torch.rand((o, i), generator=g) * 2 - 1) / i ** 0.5, (torch.rand(o, generator=g) * 2 - 1) / i ** 0.5)
+        (W1, b1), (W2, b2) = lin(64, 2), lin(25, 64)
+        enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
+                                                      "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2}, device=dev)
+        t_e = time.perf_counter()
+        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+        note = f", host-to-z encode {time.perf_counter() - t_e:.2f} s"
+        a.n_states, a.n_actions = 25, 5
+    else:
+        e = synth.synth_iid(N, a.n_states, a.n_actions, seed=seed)
+    return e, note
+
+
+def take_rows(e, mask):
+    return {k: (v[mask] if isinstance(v, np.ndarray) and v.shape[:1] == mask.shape else v) for k, v in e.items()}
+
+
+def run(a):
     import torch
     import torch.distributed as dist
     from rl_offline_simulation_amd import _lib, synth
     from rl_offline_simulation_amd.table import TransitionTable
     from rl_offline_simulation_amd.evaluators import BatchedPSRS
-    from rl_offline_simulation_amd.distributed import allreduce_estimates
+    from rl_offline_simulation_amd.distributed import allreduce_estimates, shard_episodes, shard_rollouts
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,129 +281,177 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.dist_backend)
-    _lib.load()
+    lib = _lib.load()
 
-    N, R = a.transitions, a.rollouts
-    # this rank's shard of the log: shard g is generated from seed 20221107 + g (episode-disjoint by construction)
-    if a.workload == "cartpole":
-        from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
-        e = synth.cartpole_log(N, seed=20221107 + rank)
-        enc = CartpoleBoxEncoder()
-        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
-        a.n_states, a.n_actions = 162, 2
-    elif a.workload == "grid":
-        from rl_offline_simulation_amd.encoders import HOMEREncoder
-        e = synth.grid_coords_log_fast(N, seed=20221107 + rank)
-        g = torch.Generator().manual_seed(0)  # nn.Linear's default init, fixed seed (no trained checkpoint travels)
-        lin = lambda o, i: ((torch.rand((o, i), generator=g) * 2 - 1) / i ** 0.5, (torch.rand(o, generator=g) * 2 - 1) / i ** 0.5)
-        (W1, b1), (W2, b2) = lin(64, 2), lin(25, 64)
-        enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
-                                                      "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2}, device=dev)
-        t_e = time.perf_counter()
-        e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
-        encode_s = time.perf_counter() - t_e
-        a.n_states, a.n_actions = 25, 5
+    R = a.rollouts
+    strong = a.scaling == "strong"
+    # strong: every rank derives its shard from the same log; weak: shard g is its own log, generated from seed 20221107 + g
+    e_full, enc_note = make_log(a, 20221107 + (0 if strong else rank), dev)
+    if strong and world > 1:
+        e = take_rows(e_full, shard_episodes(e_full["episode_ids"], rank, world))
     else:
-        e = synth.synth_iid(N, a.n_states, a.n_actions, seed=20221107 + rank)
+        e = e_full
     pi = synth.dirichlet_policy(a.n_states, a.n_actions)
-    t0 = e["steps"] == 0
-    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=dev)
-    pi_slots = table.policy_slots(pi)
     seeds = np.arange(R, dtype=np.uint64)
-    tile = min(a.tile, R)
-    envs = {}
-
-    def env_for(n):
-        if n not in envs:
-            envs[n] = BatchedPSRS(table, n)
-        return envs[n]
-
-    acc = {k: torch.zeros(R, dtype=dt, device=dev) for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64),
-                                                                   ("steps", torch.int64), ("cand", torch.int64))}
-    ev = []  # (kind, start, stop) HIP events on the launch stream
-
-    def one_pass(record):
-        for b in range(0, R, tile):
-            sd = seeds[b:b + tile]
-            env = env_for(len(sd))
-            if record:
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
-            env.reset_sampler(sd, a.shuffle, shuffle_seed=1234)
-            if record:
-                e1.record()
-            o = env.eval_mc(pi_slots, a.gamma)
-            if record:
-                e2.record()
-                ev.append(("reset_sampler", e0, e1))
-                ev.append(("scan", e1, e2))
-            for k in acc:
-                acc[k][b:b + len(sd)] = o[k]
-        est = torch.stack([acc["sum_g"], acc["n_ep"].to(torch.float64)], dim=1)
-        if world > 1:
-            allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096)
-        return est
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_pass(False)
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(a.steps):
-        est = one_pass(True)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    steps_t = torch.stack([acc["steps"].sum(), acc["cand"].sum()]).to(torch.float64)
-    if world > 1:
-        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)
-    elapsed = float(el_t[0])
-    steps_pass, cand_pass = float(steps_t[0]), float(steps_t[1])  # all ranks, one pass
+    def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full):
+        """n_warm + n_timed passes of seeds[seed_lo:seed_hi] over the table of e_rank.  Returns the timing, the per-kernel HIP-event
+        times and the per-seed results of the last pass."""
+        table = TransitionTable(e_rank["z"], e_rank["actions"], e_rank["rewards"], e_rank["z_next"], e_rank["terminals"],
+                                e_rank["action_distributions"], e_rank["steps"] == 0, device=dev)
+        pi_slots = table.policy_slots(pi)
+        sd_all = seeds[seed_lo:seed_hi]
+        n_loc = len(sd_all)
+        tile = max(1, min(a.tile, n_loc))
+        envs = {}
 
-    if rank == 0:
+        def env_for(n):
+            if n not in envs:
+                envs[n] = BatchedPSRS(table, n)
+            return envs[n]
+
+        acc = {k: torch.zeros(n_loc, dtype=dt, device=dev) for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64),
+                                                                           ("steps", torch.int64), ("cand", torch.int64))}
+        ev = []  # (kind, start, stop) HIP events on the launch stream (torch's current stream is the stream handed to the C ABI)
+
+        def one_pass(record):
+            for b in range(0, n_loc, tile):
+                sd = sd_all[b:b + tile]
+                env = env_for(len(sd))
+                if record:
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    e0.record()
+                env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots)
+                if record:
+                    e1.record()
+                o = env.eval_mc(pi_slots, a.gamma)
+                if record:
+                    e2.record()
+                    ev.append(("reset_sampler", e0, e1))
+                    ev.append(("scan", e1, e2))
+                for k in acc:
+                    acc[k][b:b + len(sd)] = o[k]
+            if fill_full:  # rollout-sharded: every rank owns a slice of the seeds, the all-reduce assembles the [R,2] table
+                est = torch.zeros((R, 2), dtype=torch.float64, device=dev)
+                est[seed_lo:seed_hi, 0] = acc["sum_g"]
+                est[seed_lo:seed_hi, 1] = acc["n_ep"].to(torch.float64)
+            else:
+                est = torch.stack([acc["sum_g"], acc["n_ep"].to(torch.float64)], dim=1)
+            if world > 1:
+                allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096)
+            return est
+
+        for _ in range(n_warm):
+            one_pass(False)
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(n_timed):
+            est = one_pass(True)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tot = torch.stack([acc["steps"].sum(), acc["cand"].sum()]).to(torch.float64)
+        if world > 1:
+            dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         t_scan = sum(s.elapsed_time(t) for k, s, t in ev if k == "scan") * 1e-3
         t_reset = sum(s.elapsed_time(t) for k, s, t in ev if k == "reset_sampler") * 1e-3
-        n_scan = sum(1 for k, _, _ in ev if k == "scan")
-        my_steps, my_cand = float(acc["steps"].sum()), float(acc["cand"].sum())
-        b_c = table.bytes_per_candidate + (4 if a.shuffle != "table_order" else 0)  # + permutation index
-        b_s = table.bytes_per_step
-        alg_bytes_pass = my_cand * b_c + my_steps * b_s
+        res = dict(elapsed=float(el_t[0]), steps_pass=float(tot[0]), cand_pass=float(tot[1]), t_scan=t_scan, t_reset=t_reset,
+                   n_scan=sum(1 for k, _, _ in ev if k == "scan"), my_steps=float(acc["steps"].sum()), my_cand=float(acc["cand"].sum()),
+                   est=est, acc={k: v.cpu().numpy() for k, v in acc.items()}, b_c=table.bytes_per_candidate, b_s=table.bytes_per_step,
+                   rows=table.N, tile=tile, variant=env_for(tile).scan_variant(), seg=(table.min_seg, table.max_seg))
+        del envs, table
+        torch.cuda.empty_cache()
+        return res
+
+    m = measure(e, 0, R, a.warmup, a.steps, False)
+    extra = None
+    if strong and world > 1 and not a.no_rollout_sharded:
+        lo, hi = shard_rollouts(R, rank, world)
+        x = measure(e_full, lo, hi, 1, 1, True)
+        extra = {"value": x["steps_pass"] / x["elapsed"], "unit": "simulated steps/s", "ms_per_step": x["elapsed"] * 1e3,
+                 "steps": 1, "warmup": 1, "rollouts_per_gpu": hi - lo, "transitions_per_gpu": int(x["rows"]),
+                 "scan_s_per_pass": x["t_scan"], "reset_sampler_s_per_pass": x["t_reset"],
+                 "what": "same job split the other way (SURVEY 8e primary axis): the whole log replicated on every GPU, R/N seeds per GPU, "
+                         "all-reduce assembles the [R,2] table"}
+
+    if rank == 0:
+        elapsed, t_scan, t_reset, n_scan = m["elapsed"], m["t_scan"], m["t_reset"], m["n_scan"]
+        b_c = m["b_c"] + (4 if a.shuffle != "table_order" else 0)  # + queue-order index (SURVEY 8d, mode A)
+        b_s = m["b_s"]
+        alg_bytes_pass = m["my_cand"] * b_c + m["my_steps"] * b_s
         achieved = alg_bytes_pass * a.steps / t_scan / 1e9
-        value = steps_pass * a.steps / elapsed
+        value = m["steps_pass"] * a.steps / elapsed
+        est = m["est"]
         vest = (est[:, 0] / est[:, 1]).cpu().numpy()
-        traffic, traffic_src = pmc_traffic(a)
+        kernel = m["variant"]
+        traffic, traffic_src = pmc_traffic(a, kernel, world)
+        n_rank = int(m["rows"])
+        shard_txt = ("one GPU" if world == 1 else
+                     f"the {a.transitions}-transition log split into {world} episode-disjoint shards ({n_rank} rows on rank 0), all {R} seeds on every shard, "
+                     "one RCCL all-reduce of per-seed (sum G, n episodes)" if strong else
+                     f"weak: {world} logs of {a.transitions} transitions, one per GPU, all {R} seeds on each, one RCCL all-reduce of per-seed (sum G, n episodes)")
+        wl = (f"CartPole-dynamics log, uniform logger, device box encoder (C2)" if a.workload == "cartpole" else
+              f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA with random-init weights (C3){enc_note}" if a.workload == "grid" else
+              f"S-iid synthetic log (SURVEY 8d), nS={a.n_states}, nA={a.n_actions}")
         out = {
             "metric": "simulated steps/sec (node), 10M logged transitions x 4096 rollouts",
             "value": value, "unit": "simulated steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"CartPole-dynamics log, uniform logger, device box encoder (C2), {N} transitions" if a.workload == "cartpole" else
-                                   f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA with random-init weights (C3), {N} transitions, host-to-z encode {encode_s:.2f} s" if a.workload == "grid" else f"S-iid synthetic log (SURVEY 8d), {N} transitions per GPU x {R} rollouts, nS={a.n_states}, nA={a.n_actions}, "
-                                   f"evalMC_psrs to exhaustion, gamma={a.gamma}"), "transitions_per_gpu": N, "rollouts": R,
-                       "shuffle": a.shuffle, "rollout_tile": tile, "p_log": "f32", "sharding": f"log sharded by episode over {world} GPU(s), "
-                       "all seeds on every shard, RCCL all-reduce of per-seed (sum G, n episodes)"},
-            "candidates_per_s": cand_pass * a.steps / elapsed, "acceptance": steps_pass / max(cand_pass, 1.0),
-            "buffer_consumed_frac": cand_pass / (world * R * N),
+            "config": {"workload": f"{wl}, {a.transitions} transitions {'in total' if strong else 'per GPU'} x {R} rollouts, evalMC_psrs to exhaustion, gamma={a.gamma}",
+                       "transitions": a.transitions, "transitions_on_rank0": n_rank, "rollouts": R, "shuffle": a.shuffle, "rollout_tile": m["tile"],
+                       "p_log": "f32", "sharding": shard_txt, "segment_rows_min_max": list(m["seg"])},
+            "candidates_per_s": m["cand_pass"] * a.steps / elapsed, "acceptance": m["steps_pass"] / max(m["cand_pass"], 1.0),
+            "buffer_consumed_frac": m["cand_pass"] / (R * a.transitions * (1 if strong else world)),
             "value_estimate_mean": float(np.nanmean(vest)),
-            "scan_only_steps_per_s": my_steps * a.steps / t_scan, "reset_sampler_s_per_pass": t_reset / a.steps,
+            "scan_only_steps_per_s": m["my_steps"] * a.steps / t_scan, "reset_sampler_s_per_pass": t_reset / a.steps,
             "scan_s_per_pass": t_scan / a.steps,
-            "roofline": {"bound": "hbm", "kernel": "k_eval_mc_win (offsim_eval_mc_keys)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_pass / max(n_scan / a.steps, 1),
                          "bytes_per_candidate": b_c, "bytes_per_step": b_s, "launches": n_scan,
-                         "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3},
+                         "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3, "rank": 0},
         }
+        if extra:
+            out["rollout_sharded"] = extra
+        base = None
+        if not a.no_parity_check:
+            base = oracle_for(e)
+            ps = [s for s in PARITY_SEEDS if s < R]
+            got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ps}
+            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got)
+            if not out["parity_check"]["ok"]:
+                sys.stderr.write(json.dumps(out["parity_check"]) + "\n")
+                raise SystemExit("bench.py: the GPU results differ from the oracle on this table -- no number is reported")
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(e, pi, a.gamma, min(a.cpu_sample_transitions, N), a.cpu_sample_seconds)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(base or oracle_for(e), pi, a.gamma, a.cpu_sample_seconds, a.cpu_threads_cap)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
+def main():
+    a = parse()
+    if a.print_csrc_digest:
+        print(csrc_digest())
+        return 0
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        return spawn_ranks(a)  # before any GPU call in this process
+    if env_world is not None and int(env_world) != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}; start one rank per GPU (or leave WORLD_SIZE unset and let "
+                         "bench.py start them)\n")
+        return 2
+    run(a)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -51,6 +51,7 @@ extern "C" {
 #define OFFSIM_ST_NO_INIT 2     /* PSRS.reset returned None: init queue empty                       */
 #define OFFSIM_ST_KEYERROR 3    /* current state never occurs as a from-state (psrs.py:44)          */
 #define OFFSIM_ST_INACTIVE 4    /* rollout had no current state (s is None); nothing done           */
+#define OFFSIM_ST_PROTOCOL 5    /* internal: a bounded wait of the two-wavefront scan expired (never expected) */
 
 /* The logged-transition table, SoA, rows physically grouped by from-state (CSR).  Built by
  * offsim_group_by_state + offsim_table_gather from the OfflineDataset.experience arrays
@@ -144,8 +145,10 @@ int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t
 
 /* evalMC_psrs(env, n_episodes, pi, gamma) (psrs.py:241-271) for all rollouts in one launch.
  * pi [n_slots,nA] (row s = policy in state slot s), same dtype rule as p_new.
- * gamma_pow [n_gamma_pow] f64 holds gamma**t as the host computes it (Python float ** int); the
- *   device falls back to pow() beyond it.
+ * gamma_pow [n_gamma_pow] f64 holds gamma**t as the host computes it (Python float ** int == libm pow); Gs are bit-exact
+ *   only for t inside the table.  Beyond it: if the table ends stationary (last two entries equal and 0, +-inf or 1 -- for
+ *   |gamma| < 1 the factor is exactly 0 from t ~ 7.4e4 on at gamma = 0.99) the last entry is used, which is again exact;
+ *   otherwise the device's own pow().  A table of N+1 entries always suffices (an episode has at most N steps).
  * out_sum_g[r] sum of completed episodes' returns (episode order), out_n_ep[r] their number,
  * out_steps[r] accepted steps, out_cand[r] candidates examined, out_n_len[r] entries of `lengths`
  * (n_ep or n_ep+1, psrs.py:265), out_status[r] why the rollout stopped.
@@ -211,6 +214,14 @@ int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi,
  * offsim_eval_mc_keys runs the same loop as offsim_eval_mc (OFFSIM_PROB_F64, OFFSIM_REJECT_DEFAULT) from those keys,
  * with per-state candidate windows in LDS; n_slots <= 256, otherwise OFFSIM_EUNSUPPORTED (use offsim_eval_mc). */
 int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream);
+/* Name of the kernel offsim_eval_mc_keys launches for this state count and R rollouts ("" if it would refuse): measurement
+ * code labels its roofline with it.  Two bit-identical kernels exist: k_eval_mc_win (one wavefront per rollout; the default)
+ * and k_eval_mc_split (chain + helper wavefront per rollout, picked for 256..3072 rollouts where it is 9-17 % faster).  The
+ * split kernel's two wavefronts exchange a log ring and counters through plain LDS words: it relies on the LDS unit executing
+ * one wavefront's DS instructions in issue order (so data written before a counter is visible before the counter); its waits
+ * are bounded and a stalled protocol ends the rollout with OFFSIM_ST_PROTOCOL instead of hanging the stream.
+ * OFFSIM_SCAN_SPLIT=0/1 in the environment forces a variant. */
+const char *offsim_eval_mc_keys_kernel(int32_t n_slots, int32_t R);
 int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
                         const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
                         void *stream);

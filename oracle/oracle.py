@@ -36,6 +36,8 @@ def lib():
         L.oracle_psrs_new.restype = C.c_void_p
         L.oracle_psrs_new.argtypes = [C.c_int64, C.c_int64, p64, p64, pd, p64, pu8, pu8, pd]
         L.oracle_psrs_free.argtypes = [C.c_void_p]
+        L.oracle_psrs_clone.restype = C.c_void_p
+        L.oracle_psrs_clone.argtypes = [C.c_void_p]
         L.oracle_psrs_reset_sampler.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_psrs_set_rejection_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_psrs_get_orders.argtypes = [C.c_void_p, p64, p64, p64, p64]
@@ -133,6 +135,15 @@ class OraclePSRS:
         self._h = lib().oracle_psrs_new(N, self.nA, _p(self.z, C.c_int64), _p(self.a, C.c_int64),
                                         _p(self.r, C.c_double), _p(self.z_next, C.c_int64),
                                         _p(self.done, C.c_uint8), _p(self.t0, C.c_uint8), _p(self.p_log, C.c_double))
+
+    def clone(self):
+        """A second sampler over the same buffer (shares the arrays and the grouping; own queues, cursors, streams)."""
+        o = object.__new__(OraclePSRS)
+        for k in ("z", "a", "r", "z_next", "done", "t0", "p_log", "N", "nA"):
+            setattr(o, k, getattr(self, k))
+        o._parent = self  # keeps the shared grouping alive
+        o._h = lib().oracle_psrs_clone(self._h)
+        return o
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -198,6 +198,7 @@ typedef struct {
     int64_t cur_z;
     int64_t cur_row; /* row whose next-observation is the current s; -1 after reset */
     int64_t cur_init_row;
+    int shares_grouping; /* grouped/keys/key_off belong to another object (oracle_psrs_clone) */
 } psrs_t;
 
 typedef struct {
@@ -254,11 +255,25 @@ psrs_t *oracle_psrs_new(int64_t N, int64_t nA, const int64_t *z, const int64_t *
     p->has_state = 0;
     return p;
 }
+/* Another sampler over the same buffer: shares the read-only grouping of `src` (which must outlive it) and owns its
+ * queues, cursors and streams.  For callers that run one rollout per thread over one big log (bench.py's CPU baseline). */
+psrs_t *oracle_psrs_clone(const psrs_t *src) {
+    psrs_t *p = (psrs_t *)malloc(sizeof(psrs_t));
+    *p = *src;
+    p->shares_grouping = 1;
+    p->queue = (int64_t *)malloc(sizeof(int64_t) * (size_t)(p->N > 0 ? p->N : 1));
+    p->head = (int64_t *)calloc((size_t)(p->n_keys + 1), sizeof(int64_t));
+    p->init_q = (int64_t *)malloc(sizeof(int64_t) * (size_t)(p->n_init > 0 ? p->n_init : 1));
+    p->has_state = 0;
+    return p;
+}
 void oracle_psrs_free(psrs_t *p) {
     if (!p) return;
-    free(p->grouped);
-    free(p->keys);
-    free(p->key_off);
+    if (!p->shares_grouping) {
+        free(p->grouped);
+        free(p->keys);
+        free(p->key_off);
+    }
     free(p->queue);
     free(p->head);
     free(p->init_q);

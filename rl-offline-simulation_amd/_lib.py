@@ -13,7 +13,7 @@ OK = 0
 F32, F64, F16 = 0, 1, 2
 REJECT_DEFAULT, REJECT_NEVER = 0, 1
 PROB_F64, PROB_F32 = 0, 1
-ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE = 0, 1, 2, 3, 4
+ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE, ST_PROTOCOL = 0, 1, 2, 3, 4, 5
 
 _vp, _i32, _i64, _u8 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint8
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     "offsim_eval_td": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), C.POINTER(TD), _vp]),
     "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
+    "offsim_eval_mc_keys_kernel": (C.c_char_p, [_i32, _i32]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),

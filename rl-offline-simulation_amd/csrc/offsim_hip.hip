@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "offsim.h"
+#include "discount.hpp"
 #include "pcg64_dev.hpp"
 #include "shuffle_wave.hpp"
 
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
         int64_t tt = 0;
         bool done = false;
         while (!done) {
-            const double gp = tt < n_gamma_pow ? gamma_pow[tt] : pow(gamma, (double)tt);  // issued ahead of the step
+            const double gp = discount_at(gamma_pow, (uint64_t)n_gamma_pow, gamma, (uint64_t)tt);  // issued ahead of the step
             StepResult s = psrs_step<PL, PROB>(t, seg_lds, perm_row, slot, cur_lds, pi_lds + (size_t)slot * nA, reject_mode, 0u,
                                                rng, consumed);
             cand += s.popped;
@@ -1002,6 +1003,20 @@ extern "C" int offsim_compile_policy(const offsim_table *t, const double *pi, ui
     return OFFSIM_OK;
 }
 
+// Which of the two scan kernels serves R rollouts (both are bit-identical; the parity suite runs against each):
+// the one-wavefront kernel k_eval_mc_win is the default -- R = 1 drop-in calls, small batches, and the headline size, where the
+// CU is at its instruction-issue ceiling; the two-wavefront kernel (scan_split.hpp: chain wave + helper wave per rollout) takes
+// the sizes where it is measurably faster, 256..3072 rollouts per GPU (17 % at <= 1024, 9 % at 3072, 7 % slower at 4096).
+// OFFSIM_SCAN_SPLIT=0/1 forces a variant.
+static bool scan_uses_split(int32_t R) {
+    static const int split_mode = getenv("OFFSIM_SCAN_SPLIT") ? atoi(getenv("OFFSIM_SCAN_SPLIT")) : -1;
+    return split_mode == 1 || (split_mode < 0 && R >= 256 && R <= 3072);
+}
+extern "C" const char *offsim_eval_mc_keys_kernel(int32_t n_slots, int32_t R) {
+    if (n_slots > 256) return "";
+    return scan_uses_split(R) ? "k_eval_mc_split" : "k_eval_mc_win";
+}
+
 extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
                                    const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
                                    const offsim_evalmc_out *out, void *stream) {
@@ -1030,10 +1045,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
                                n_gamma_pow, max_episodes, *out);                                                      \
     } while (0)
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
-    // chain wave + helper wave per rollout (scan_split.hpp) while that leaves the CU below its instruction-issue ceiling:
-    // 17 % faster at <= 1024 rollouts, 9 % at 3072, 7 % slower at 4096.  OFFSIM_SCAN_SPLIT=0/1 overrides.
-    static const int split_mode = getenv("OFFSIM_SCAN_SPLIT") ? atoi(getenv("OFFSIM_SCAN_SPLIT")) : -1;
-    const bool split = split_mode == 1 || (split_mode < 0 && ro->R <= 3072);
+    const bool split = scan_uses_split(ro->R);
     if (split) {
 #define LAUNCH_SPLIT(W, ROUNDS)                                                                                       \
     do {                                                                                                              \

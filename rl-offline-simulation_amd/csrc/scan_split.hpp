@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(512, 8)
                 g = perm_row ? perm_row[p] : p;
                 const uint64_t below = done_mask & ((1ull << lane) - 1ull);
                 const uint32_t t_log = below ? (uint32_t)lane - 1u - (63u - (uint32_t)__clzll((long long)below)) : tt_chain + (uint32_t)lane;
-                gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
+                gp = discount_at(gamma_pow, n_gamma_pow, gamma, t_log);
             }
             g1 = g;
             gp1 = gp;

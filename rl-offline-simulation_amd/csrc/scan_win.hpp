@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "discount.hpp"
 #include "offsim.h"
 #include "pcg64_dev.hpp"
 
@@ -43,7 +44,6 @@ __device__ __forceinline__ uint64_t key_T(uint64_t key) { return ((key >> 43) <<
 __device__ __forceinline__ uint64_t exact_draw53(U128 base, U128 inc, uint64_t n_steps) {
     return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
 }
-__device__ __forceinline__ double pow_fallback(double gamma, double t) { return pow(gamma, t); }
 
 template <typename PL>
 __global__ void k_compile_policy(offsim_table t, const double *__restrict__ pi, uint64_t *__restrict__ keys) {
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256, 4)
                 g = perm_row ? perm_row[p] : p;              // accepted row, through the rollout's permutation
                 const uint64_t below = done_mask & ((1ull << lane) - 1ull);  // episode ends earlier in this phase
                 const uint32_t t_log = below ? (uint32_t)lane - 1u - (63u - (uint32_t)__clzll((long long)below)) : tt_chain + (uint32_t)lane;
-                gp = t_log < n_gamma_pow ? gamma_pow[t_log] : pow(gamma, (double)t_log);
+                gp = discount_at(gamma_pow, n_gamma_pow, gamma, t_log);
             }
             g1 = g;
             gp1 = gp;

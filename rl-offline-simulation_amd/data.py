@@ -2,6 +2,7 @@
 (offsim4rl/data.py:16-118).  HDF5 I/O and SAS_Dataset are storage / encoder-training helpers
 outside the replay-loop path and are not reproduced."""
 import enum
+import json
 import logging
 from collections import namedtuple
 
@@ -68,33 +69,116 @@ class OfflineDataset:
     # ---- ingestion formats ----
     # The reference stores datasets as HDF5: one gzip dataset per experience key, the spaces and the
     # ProbDistribution pickled into group attributes (data.py:85-98, 120-146).  h5py is not part of this stack, so
-    # the native container here is .npz with the same keys; HDF5 files written by the reference load through
-    # load_hdf5 wherever h5py is importable.
+    # the native container here is .npz with the same keys and the spaces described in JSON (nothing is unpickled on
+    # load); HDF5 files written by the reference load through load_hdf5 wherever h5py is importable.
     def save_npz(self, path):
-        import pickle
-        meta = np.frombuffer(pickle.dumps((self.observation_space, self.action_space, self.action_dist_type)), dtype=np.uint8)
-        np.savez_compressed(path, __spaces__=meta, **{k: np.asarray(v) for k, v in self.experience.items()})
+        meta = json.dumps({"observation_space": _space_to_json(self.observation_space), "action_space": _space_to_json(self.action_space),
+                           "action_dist_type": ProbDistribution(self.action_dist_type).name})
+        np.savez_compressed(path, __spaces__=np.frombuffer(meta.encode(), dtype=np.uint8), **{k: np.asarray(v) for k, v in self.experience.items()})
 
     @classmethod
     def load_npz(cls, path):
-        import pickle
         with np.load(path, allow_pickle=False) as z:
-            obs_space, act_space, dist_type = pickle.loads(z["__spaces__"].tobytes())
-            return cls(obs_space, act_space, dist_type, **{k: z[k] for k in z.files if k != "__spaces__"})
+            meta = json.loads(z["__spaces__"].tobytes().decode())
+            return cls(_space_from_json(meta["observation_space"]), _space_from_json(meta["action_space"]),
+                       ProbDistribution[meta["action_dist_type"]], **{k: z[k] for k in z.files if k != "__spaces__"})
 
     @classmethod
     def load_hdf5(cls, path, group_name=None):
-        """data.py:81-83 / HDF5Dataset (data.py:120-146): arrays are read into memory (the device table copies them anyway)."""
+        """data.py:81-83 / HDF5Dataset (data.py:120-146): arrays are read into memory (the device table copies them anyway).
+        The `infos/<key>` datasets written by record_dataset_in_memory (utils/dataset_utils.py:83-113) come back as experience
+        keys "infos/<key>".  The pickled gym.spaces attributes are decoded by a restricted unpickler onto spaces.Discrete / Box."""
         try:
             import h5py
         except ImportError as e:  # pragma: no cover - h5py is absent from the build image
             raise ImportError("load_hdf5 needs h5py; convert with the reference's tools or use save_npz/load_npz") from e
-        import pickle
         with h5py.File(path, "r") as fin:
-            group = fin.get(group_name, default=fin) if group_name else fin
+            group = fin[group_name] if group_name else fin
+            return cls.from_hdf5_group(group)
 
-            def attr(name, default=None):
-                b = group.attrs.get(name, default=None)
-                return pickle.loads(b.tobytes()) if b is not None else default
-            return cls(attr("observation_space"), attr("action_space"), attr("action_dist_type", ProbDistribution.NoProbability),
-                       **{k: np.asarray(group[k]) for k in group})
+    @classmethod
+    def from_hdf5_group(cls, group):
+        """Any h5py-like group: `.attrs` mapping with the pickled spaces, datasets by key, sub-groups flattened to "a/b"."""
+        def attr(name, default=None):
+            b = group.attrs.get(name, None)
+            return default if b is None else restricted_loads(b.tobytes() if hasattr(b, "tobytes") else bytes(b))
+
+        exp = {}
+
+        def walk(g, prefix):
+            for k in g:
+                v = g[k]
+                if hasattr(v, "keys") and not hasattr(v, "shape"):
+                    walk(v, prefix + k + "/")
+                else:
+                    exp[prefix + k] = np.asarray(v)
+        walk(group, "")
+        return cls(attr("observation_space"), attr("action_space"), attr("action_dist_type", ProbDistribution.NoProbability), **exp)
+
+
+def _space_to_json(sp):
+    if sp is None:
+        return None
+    if hasattr(sp, "n") and not hasattr(sp, "low"):
+        return {"kind": "Discrete", "n": int(sp.n)}
+    if hasattr(sp, "low") and hasattr(sp, "high"):
+        return {"kind": "Box", "shape": [int(x) for x in sp.shape], "dtype": np.dtype(sp.dtype).name,
+                "low": np.asarray(sp.low, np.float64).reshape(-1).tolist(), "high": np.asarray(sp.high, np.float64).reshape(-1).tolist()}
+    raise ValueError(f"cannot describe space {sp!r}: only Discrete and Box are part of the OfflineDataset schema")
+
+
+def _space_from_json(d):
+    from . import spaces
+    if d is None:
+        return None
+    if d["kind"] == "Discrete":
+        return spaces.Discrete(d["n"])
+    shape = tuple(d["shape"])
+    dt = np.dtype(d["dtype"])
+    return spaces.Box(np.array(d["low"], np.float64).reshape(shape).astype(dt), np.array(d["high"], np.float64).reshape(shape).astype(dt), shape, dt.type)
+
+
+class _PickledSpace:
+    """Receives the state of a pickled gym.spaces.Discrete / Box (their __reduce_ex__ is object.__reduce_ex__: class + __dict__)."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else state[0] or {})
+
+    def resolve(self):
+        from . import spaces
+        d = self.__dict__
+        if "n" in d:
+            return spaces.Discrete(int(d["n"]))
+        shape = tuple(d.get("_shape", d.get("shape", np.shape(d["low"]))))
+        return spaces.Box(d["low"], d["high"], shape, np.dtype(d.get("dtype", np.float32)).type)
+
+
+def restricted_loads(data):
+    """pickle.loads for the attributes the reference stores in its HDF5 files (data.py:88-91): gym.spaces.Discrete / Box map
+    onto this package's spaces, offsim4rl.data.ProbDistribution onto the local enum, NumPy array / dtype reconstruction is
+    allowed, everything else is refused -- a data file cannot name arbitrary callables."""
+    import io
+    import pickle
+
+    allowed_numpy = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+                     ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                     ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] in ("gym", "gymnasium") and name in ("Discrete", "Box"):
+                return _PickledSpace
+            if name == "ProbDistribution":
+                return ProbDistribution
+            if (module, name) in allowed_numpy:
+                import importlib
+                return getattr(importlib.import_module(module), name)
+            if module.startswith("numpy") and name in ("float32", "float64", "int64", "int32", "uint8", "bool_"):
+                return getattr(np, name)
+            if (module, name) == ("copyreg", "_reconstructor") or (module, name) == ("builtins", "object"):
+                import copyreg
+                return copyreg._reconstructor if name == "_reconstructor" else object
+            raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a dataset file")
+
+    obj = U(io.BytesIO(data)).load()
+    return obj.resolve() if isinstance(obj, _PickledSpace) else obj

@@ -22,10 +22,27 @@ SHUFFLE_SHARED = "shared"            # one queue order (shuffle_seed) shared by 
 SHUFFLE_NONE = "table_order"         # queues in buffer order (no shuffle); per-rollout rejection streams
 
 
-def _gamma_pow(gamma, n, device):
-    """gamma**t exactly as the host computes it for the reference (Python float ** int, psrs.py:262)."""
+_GP_CACHE = {}
+
+
+def _gamma_pow(gamma, n, device, cap=None):
+    """gamma**t exactly as the host computes it for the reference (Python float ** int == libm pow, psrs.py:262), for every
+    t an episode can reach: at least `n` entries, then on until the factor is stationary (0, inf or 1: the device clamps t to
+    the last entry in that case, csrc/discount.hpp) or `cap` entries (an episode has at most N steps) are there."""
     g = float(gamma)
-    return torch.tensor([g ** t for t in range(n)], dtype=torch.float64, device=device)
+    cap = max(int(n), 2) if cap is None else max(int(cap), int(n), 2)
+    key = (g, int(n), cap, str(device))
+    if key not in _GP_CACHE:
+        vals = [g ** t for t in range(max(int(n), 2))]
+        while len(vals) < cap and not (vals[-1] == vals[-2] and (vals[-1] in (0.0, 1.0) or vals[-1] in (float("inf"), float("-inf")))):
+            t0 = len(vals)
+            vals.extend(g ** t for t in range(t0, min(cap, t0 + 65536)))
+        while len(vals) > max(int(n), 2) and vals[-1] == vals[-2] == vals[-3] and vals[-1] in (0.0, 1.0, float("inf"), float("-inf")):
+            vals.pop()  # (extended in blocks: keep exactly two stationary entries)
+        if len(_GP_CACHE) > 64:
+            _GP_CACHE.clear()
+        _GP_CACHE[key] = torch.tensor(vals, dtype=torch.float64, device=device)
+    return _GP_CACHE[key]
 
 
 def _prob_mode(table, p_dtype):
@@ -48,7 +65,9 @@ class BatchedPSRS:
         self._init_perm_buf = None
 
     # -- PSRS.reset_sampler (psrs.py:19-30) for all rollouts --
-    def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None):
+    def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None):
+        """`policy` (optional, [n_slots,nA]): the tabular policy the following eval_mc calls will evaluate.  It changes no
+        result; it lets the sampler reset lay the queue orders out for that evaluation."""
         t, dev = self.table, self.table.device
         sd = seeds_tensor(seeds, dev)
         assert sd.numel() == self.R, "one seed per rollout"
@@ -148,7 +167,7 @@ class BatchedPSRS:
             o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
         if dbg:
             o["dbg"] = torch.zeros((R, 4), dtype=torch.int64, device=dev)
-        gp = _gamma_pow(gamma, n_gamma_pow, dev)
+        gp = _gamma_pow(gamma, n_gamma_pow, dev, cap=t.N + 2)
         oc = L.EvalMCOut(dbg=L.ptr(o.get("dbg")), sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
@@ -188,7 +207,7 @@ class BatchedPSRS:
             o["trace_row"] = torch.full((R, trace_cap), -1, dtype=torch.int32, device=dev)
             o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
             o["td_err"] = torch.zeros((R, trace_cap), dtype=torch.float64, device=dev)
-        gp = _gamma_pow(gamma, n_gamma_pow, dev)
+        gp = _gamma_pow(gamma, n_gamma_pow, dev, cap=t.N + 2)
         oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")), ep_len=L.ptr(o.get("ep_len")),
                          ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")), trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
@@ -198,6 +217,10 @@ class BatchedPSRS:
         o["q"] = q
         o["_keepalive"] = (pi_d, gp)
         return o
+
+    def scan_variant(self):
+        """Name of the kernel eval_mc's fast path launches for this table and batch size (measurement label)."""
+        return L.load().offsim_eval_mc_keys_kernel(self.table.n_slots, self.R).decode() or "k_eval_mc"
 
     def compile_policy(self, pi_d):
         """offsim_compile_policy: one 64-bit key per grouped row for the tabular policy pi_d [n_slots,nA] f64 (device)."""
@@ -384,7 +407,7 @@ class PSRS:
         out = {}
         for s in range(self.table.n_slots):
             if seg[s + 1] > seg[s]:
-                out[s + self.table.z_base] = [int(order[g]) for g in perm[seg[s] + cur[s]: seg[s + 1]]]
+                out[self.table.z_of(s)] = [int(order[g]) for g in perm[seg[s] + cur[s]: seg[s + 1]]]
         return out
 
     @property
@@ -409,16 +432,16 @@ def evalMC_psrs(env, n_episodes, pi, gamma):
     built in, the whole loop runs in one kernel launch; otherwise the reference's host loop drives env.step."""
     if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and isinstance(pi, np.ndarray) and pi.ndim == 2:
         t = env.table
-        if pi.shape[0] <= t.z_base + t.n_slots - 1:
+        if t.N and pi.shape[0] <= int(t.slot_z.max()):
             raise IndexError("pi has no row for some latent state")
         n_ep = int(min(n_episodes, t.N0 + 1))
         o = env._env.eval_mc(t.policy_slots(pi), gamma, n_ep, ep_cap=max(n_ep, 1))
         status = int(o["status"].cpu()[0])
         if status == L.ST_KEYERROR:
-            raise KeyError(int(env._env.state.cur_slot.cpu()[0]) + t.z_base)
+            raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
         ne, nl = int(o["n_ep"].cpu()[0]), int(o["n_len"].cpu()[0])
         cs = int(env._env.state.cur_slot.cpu()[0])
-        env.z = cs + t.z_base if cs >= 0 else env.z
+        env.z = t.z_of(cs) if cs >= 0 else env.z
         if cs < 0:
             env.s = None
         return o["ep_g"].cpu().numpy()[0, :ne].copy(), o["ep_len"].cpu().numpy()[0, :nl].astype(np.int64)
@@ -457,7 +480,7 @@ def _q_to_slots(table, Q):
 def _slots_to_q(table, q_slots, Q):
     Q = np.array(Q, dtype=np.float64, copy=True)
     for s in range(table.n_slots):
-        z = s + table.z_base
+        z = table.z_of(s)
         if -Q.shape[0] <= z < Q.shape[0]:
             Q[z] = q_slots[s]
     return Q
@@ -479,7 +502,7 @@ def _td_device(env, n_episodes, p_rows, gamma, alpha, mode, Q_init):
                          ep_cap=n_ep + 1, trace_cap=t.N + 1)
     status = int(o["status"].cpu()[0])
     if status == L.ST_KEYERROR:
-        raise KeyError(int(env._env.state.cur_slot.cpu()[0]) + t.z_base)
+        raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
     ne, steps = int(o["n_ep"].cpu()[0]), int(o["steps"].cpu()[0])
     n_g = ne + (1 if status == L.ST_EXHAUSTED else 0)  # the cut-short episode's return is appended too (psrs.py:177, :232)
     Q = _slots_to_q(t, o["q"].cpu().numpy()[0], Q0)
@@ -500,7 +523,7 @@ def qlearn_psrs(env, n_episodes, behavior_policy, gamma, alpha=0.1, epsilon=1.0,
         fixed = _fixed_behaviour(behavior_policy, env.nA, epsilon)
     if fixed is not None:
         t = env.table
-        p_rows = np.tile(np.asarray(fixed, dtype=np.float64), (max(env.nS, t.z_base + t.n_slots), 1))
+        p_rows = np.tile(np.asarray(fixed, dtype=np.float64), (max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1), 1))
         Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, p_rows, gamma, alpha, L.TD_QLEARN, Q_init)
         return Q, {"Gs": Gs, "Qs": np.array([Q0]), "TD_errors": td, "memory": _memory(env, rows, lambda z: fixed)}
     epsilon_func = epsilon if callable(epsilon) else (lambda episode: epsilon)

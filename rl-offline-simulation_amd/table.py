@@ -75,16 +75,34 @@ class TransitionTable:
         r = _dev(r, device)
         if r.dtype not in (torch.float32, torch.float64):
             r = r.to(torch.float64)
-        # states -> non-negative slots; z = -1 is a legal key (heuristic.py:23-24)
+        # states -> non-negative slots; z = -1 is a legal key (heuristic.py:23-24).  Dense ids map to slot = z - z_base; sparse
+        # or hashed ids (the reference keys a dict by z, psrs.py:26, so any integers work there) are compacted to their rank
+        # among the distinct ids, so that the per-rollout cursor arrays and the LDS carve-outs stay proportional to the
+        # number of states and not to the id range.  slot_z[slot] is the id either way.
         if N:
             lo = int(min(z.min().item(), z_next.min().item(), 0))
             hi = int(max(z.max().item(), z_next.max().item()))
+            uniq = torch.unique(torch.cat([z, z_next]))
         else:
-            lo, hi = 0, 0
-        self.z_base = lo
-        self.n_slots = hi - lo + 1
-        slot = (z - lo).to(torch.int32).contiguous()
-        slot_next = (z_next - lo).to(torch.int32).contiguous()
+            lo, hi, uniq = 0, 0, z
+        if N and (hi - lo + 1) > max(1024, 4 * int(uniq.numel())):
+            self.z_base = None
+            self.slot_z = uniq.cpu().numpy().astype(np.int64)
+            self.n_slots = int(uniq.numel())
+            slot = torch.searchsorted(uniq, z).to(torch.int32).contiguous()
+            slot_next = torch.searchsorted(uniq, z_next).to(torch.int32).contiguous()
+        else:
+            self.z_base = lo
+            self.n_slots = hi - lo + 1
+            self.slot_z = np.arange(lo, hi + 1, dtype=np.int64)
+            slot = (z - lo).to(torch.int32).contiguous()
+            slot_next = (z_next - lo).to(torch.int32).contiguous()
+        # actions index p_log[row] and p_new on the device: NumPy would raise IndexError (or wrap a negative index) where
+        # the kernels would read out of bounds, so the range is checked here (psrs.py:54-57)
+        a_dev = _dev(a, device, torch.int64)
+        if N and (int(a_dev.min().item()) < -self.nA or int(a_dev.max().item()) >= self.nA):
+            raise IndexError(f"logged action outside [-{self.nA}, {self.nA}) for action_distributions with {self.nA} columns")
+        a = torch.where(a_dev < 0, a_dev + self.nA, a_dev).to(torch.int32)  # NumPy's negative-index wrap
         self.seg_off, self.order = group_by_state(slot, self.n_slots)
         self.p_log = gather_rows(p_log, self.order)
         self.a = gather_rows(_dev(a, device, torch.int32), self.order)
@@ -126,7 +144,16 @@ class TransitionTable:
         return self.r.element_size() + 4 + 1
 
     def slot_of(self, z):
-        return int(z) - self.z_base
+        """Slot of latent state z; -1 if z occurs nowhere in the log (its queue is missing: KeyError at the next step, psrs.py:44)."""
+        z = int(z)
+        if self.z_base is not None:
+            s = z - self.z_base
+            return s if 0 <= s < self.n_slots else -1
+        i = int(np.searchsorted(self.slot_z, z))
+        return i if i < self.n_slots and int(self.slot_z[i]) == z else -1
+
+    def z_of(self, slot):
+        return int(self.slot_z[int(slot)])
 
     def segment_lengths(self):
         so = self.seg_off.to(torch.int64).cpu().numpy() & 0xFFFFFFFF
@@ -136,7 +163,7 @@ class TransitionTable:
         """Rows of a tabular policy indexed as the reference does, pi[S] with NumPy semantics
         (S = -1 selects the last row; psrs.py:255): returns pi_slots[n_slots, nA]."""
         pi = np.asarray(pi)
-        zs = np.arange(self.z_base, self.z_base + self.n_slots)
+        zs = self.slot_z
         idx = np.where(zs < 0, zs + pi.shape[0], zs)
         ok = (idx >= 0) & (idx < pi.shape[0])
         out = np.zeros((self.n_slots, pi.shape[1]), pi.dtype)

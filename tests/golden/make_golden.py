@@ -268,6 +268,10 @@ def main():
         inp["r"] = inp["r"].astype(np.float64)
         psrs_fixture(nm, inp, [0, 1], pi=pi162, gamma=0.99, p_new_step=np.array([0.5, 0.5]))
 
+    # ---- 10b. episodes longer than 4096 steps (two done rows in 30 k): gamma**t far beyond any small table (psrs.py:262) ----
+    long_ep = case_inputs(synth.synth_iid(30000, 25, 5, seed=34, p_done=1.0 / 8000))
+    psrs_fixture("iid_30k_long_episodes", long_ep, [0, 1], pi=pi25, gamma=0.999, store_orders=False)
+
     # ---- 11. learner-in-the-loop drivers (psrs.py:119-239) with a Q-independent behaviour policy ----
     ref_tab = _load("ref_tabular", os.path.join(REF, "offsim4rl/agents/tabular.py"))
     for nm, inp, pi_t, gam in (("td_iid_2k", iid2k, pi25, 0.9), ("td_grid_300x15", grid_big, pi25, 0.95)):

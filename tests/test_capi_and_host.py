@@ -147,7 +147,7 @@ def test_policy_slots_numpy_indexing():
     from rl_offline_simulation_amd.table import TransitionTable
 
     class T:  # only the fields policy_slots reads
-        z_base, n_slots = -1, 4
+        z_base, n_slots, slot_z = -1, 4, np.arange(-1, 3)
     pi = np.arange(8.0).reshape(4, 2)
     out = TransitionTable.policy_slots(T, pi)
     assert np.array_equal(out[0], pi[-1]) and np.array_equal(out[1:], pi[:3])
@@ -165,3 +165,83 @@ def test_dataset_npz_round_trip(tmp_path):
     assert back.action_space.n == 2 and back.observation_space.shape == (4,) and back.action_dist_type == ProbDistribution.Discrete
     for k in keys:
         assert np.array_equal(back.experience[k], e[k]) and back.experience[k].dtype == e[k].dtype
+
+
+def test_hdf5_attributes_load_through_a_restricted_unpickler():
+    """The reference pickles gym.spaces objects and the ProbDistribution enum into HDF5 attributes (data.py:88-91).  gym is
+    not part of this stack: a stand-in module with the same qualified names produces the bytes, restricted_loads maps them
+    onto this package's spaces, and a payload that names any other callable is refused."""
+    import pickle
+    import sys
+    import types
+    from rl_offline_simulation_amd import ProbDistribution
+    from rl_offline_simulation_amd.data import restricted_loads
+    gym = types.ModuleType("gym")
+    sp = types.ModuleType("gym.spaces")
+    disc, box = types.ModuleType("gym.spaces.discrete"), types.ModuleType("gym.spaces.box")
+
+    class Discrete:
+        def __init__(self, n):
+            self.n, self._shape, self.dtype, self._np_random = n, (), np.dtype(np.int64), None
+
+    class Box:
+        def __init__(self, low, high):
+            self.low, self.high, self._shape, self.dtype = low, high, low.shape, np.dtype(np.float32)
+            self.bounded_below, self.bounded_above = low > -np.inf, high < np.inf
+
+    Discrete.__module__, Discrete.__qualname__ = "gym.spaces.discrete", "Discrete"
+    Box.__module__, Box.__qualname__ = "gym.spaces.box", "Box"
+    disc.Discrete, box.Box = Discrete, Box
+    mods = {"gym": gym, "gym.spaces": sp, "gym.spaces.discrete": disc, "gym.spaces.box": box}
+    sys.modules.update(mods)
+    try:
+        b_disc = pickle.dumps(Discrete(5))
+        b_box = pickle.dumps(Box(np.full(4, -2.5, np.float32), np.full(4, 2.5, np.float32)))
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    d = restricted_loads(b_disc)
+    assert d.n == 5 and type(d).__module__.endswith("spaces")
+    b = restricted_loads(b_box)
+    assert b.shape == (4,) and np.array_equal(b.low, np.full(4, -2.5, np.float32)) and np.array_equal(b.high, np.full(4, 2.5, np.float32))
+    assert restricted_loads(pickle.dumps(ProbDistribution.Discrete)) == ProbDistribution.Discrete
+    with pytest.raises(pickle.UnpicklingError):
+        restricted_loads(pickle.dumps(print))
+    with pytest.raises(pickle.UnpicklingError):
+        restricted_loads(b"cos\nsystem\n(S'true'\ntR.")
+
+
+def test_hdf5_group_layout_with_infos():
+    """The group layout save_hdf5 / record_dataset_in_memory write (data.py:85-98, utils/dataset_utils.py:83-113): one dataset
+    per key, `infos/<key>` in a sub-group, pickled spaces in attrs -- read through from_hdf5_group from a dict-shaped stand-in
+    for h5py (absent here)."""
+    import pickle
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution
+
+    class Group(dict):
+        attrs = {}
+
+    g = Group(observations=np.zeros((6, 4), np.float32), next_observations=np.ones((6, 4), np.float32), actions=np.arange(6) % 2,
+              rewards=np.ones(6, np.float32), terminals=np.zeros(6, bool), steps=np.arange(6), episode_ids=np.zeros(6, np.int64),
+              action_distributions=np.full((6, 2), 0.5, np.float32))
+    infos = Group()
+    infos["TimeLimit.truncated"] = np.zeros(6, bool)
+    g["infos"] = infos
+    g.attrs = {"action_dist_type": np.frombuffer(pickle.dumps(ProbDistribution.Discrete), np.uint8)}
+    ds = OfflineDataset.from_hdf5_group(g)
+    assert ds.action_dist_type == ProbDistribution.Discrete and ds.observation_space is None
+    assert set(ds.experience) == set(g) - {"infos"} | {"infos/TimeLimit.truncated"}
+    assert len(ds) == 6
+
+
+def test_discount_table_runs_until_the_factor_is_stationary():
+    """gamma**t comes from the host (psrs.py:262: Python float ** int) for every t an episode can reach: the table stops at
+    N + 2 entries or once the factor has become exactly 0 / 1 / inf, whichever is first (csrc/discount.hpp clamps there)."""
+    import torch
+    from rl_offline_simulation_amd.evaluators.psrs import _gamma_pow
+    gp = _gamma_pow(0.99, 4096, torch.device("cpu"), cap=10 ** 7).numpy()
+    assert gp[-1] == 0.0 and gp[-2] == 0.0 and gp[-3] > 0.0 and 70_000 < len(gp) < 80_000
+    assert all(gp[t] == 0.99 ** t for t in (0, 1, 4095, 4096, 50_000, len(gp) - 3))
+    assert len(_gamma_pow(0.99, 4096, torch.device("cpu"), cap=5000)) == 5000  # an episode cannot be longer than the log
+    assert len(_gamma_pow(1.0, 16, torch.device("cpu"), cap=10 ** 6)) == 16     # already stationary
+    assert len(_gamma_pow(0.5, 4096, torch.device("cpu"), cap=10 ** 6)) == 4096

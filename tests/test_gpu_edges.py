@@ -158,12 +158,14 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
 
 @pytest.mark.parametrize("variant", ["0", "1"])
 def test_both_scan_variants_pass_the_parity_suite(variant, gpu):
-    """The library picks csrc/scan_split.hpp (chain wave + helper wave per rollout) for <= 3072 rollouts and the
-    monolithic csrc/scan_win.hpp above; OFFSIM_SCAN_SPLIT=0/1 forces one of them and is read once per process: run the
-    golden-fixture parity tests in a child process with each."""
+    """offsim_eval_mc_keys has two bit-identical kernels (csrc/scan_win.hpp, one wavefront per rollout: the default; and
+    csrc/scan_split.hpp, chain wave + helper wave: picked for 256..3072 rollouts).  OFFSIM_SCAN_SPLIT=0/1 forces one of them
+    and is read once per process: the golden-fixture parity tests, the config tests and the edge cases of this file all run
+    in a child process with each."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, OFFSIM_SCAN_SPLIT=variant)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_configs.py"),
+                        os.path.join(here, "test_gpu_edges.py"), "-m", "gpu", "-x", "-q", "-k", "not both_scan_variants"],
+                       env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

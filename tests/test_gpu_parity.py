@@ -30,7 +30,7 @@ def golden_orders(table, perm_row, init_perm_row):
     seg = table.seg_off.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     order = table.order.cpu().numpy().astype(np.int64)
     lens = np.diff(seg)
-    keys = np.nonzero(lens)[0] + table.z_base
+    keys = table.slot_z[np.nonzero(lens)[0]]
     off = np.concatenate([[0], np.cumsum(lens[lens > 0])])
     q = order[perm_row.cpu().numpy().astype(np.int64) & 0xFFFFFFFF][: table.N]
     init = table.init_orig.cpu().numpy().astype(np.int64)[init_perm_row.cpu().numpy().astype(np.int64)][: table.N0]

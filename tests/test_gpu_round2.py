@@ -1,0 +1,326 @@
+"""GPU parity tests added in round 2: the usage-contract path through the facade with an encoder (a6), the batched step
+primitive with R > 1 (a4/f4), the headline kernel instance on a headline-size table, and two ranks of the HIP path feeding
+the all-reduce (e)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from common import load
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    from rl_offline_simulation_amd import _lib
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a6: PerStateRejectionSampling(dataset, num_states=162, encoder=CartpoleBoxEncoder(), new_step_api=True)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("new_api", [True, False])
+def test_facade_with_encoder_runs_the_usage_contract(new_api, gpu):
+    """examples/cartpole/psrs_from_expert_heuristic.py:57-80 of the reference: the evaluator is built from an OfflineDataset
+    of raw observations plus an encoder (per_state_rejection.py:28-50) and driven with step_dist until exhaustion.  The log
+    is the one behind tests/golden/cartpole_2k.npz (synth.cartpole_log(2000, seed=3)); the rows served must be the rows the
+    reference served for the same sampler seed, and every returned field must be that row's."""
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces, synth
+    from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+    from rl_offline_simulation_amd.evaluators import PerStateRejectionSampling
+    d = load("cartpole_2k")
+    e = synth.cartpole_log(2000, seed=3)
+    enc = CartpoleBoxEncoder()
+    assert np.array_equal(np.asarray(enc.encode(e["observations"])), d["in_z"])  # same latent states as the reference's encoder
+    ds = OfflineDataset(
+        observation_space=spaces.Box(low=-np.inf, high=np.inf, shape=(4,), dtype=np.float32), action_space=spaces.Discrete(2),
+        action_dist_type=ProbDistribution.Discrete, observations=e["observations"], actions=e["actions"],
+        action_distributions=e["action_distributions"], rewards=e["rewards"], next_observations=e["next_observations"],
+        terminals=e["terminals"], steps=e["steps"], episode_ids=e["episode_ids"])
+    with pytest.raises(ValueError):
+        PerStateRejectionSampling(ds, num_states=162)  # encoder missing (per_state_rejection.py:19-22)
+    with pytest.raises(ValueError):
+        PerStateRejectionSampling(ds)  # continuous observations need an encoder (:16-18)
+    psrs = PerStateRejectionSampling(ds, num_states=162, encoder=enc, new_step_api=new_api)
+    assert psrs.observation_space is ds.observation_space and psrs.action_space.n == 2
+    p_new = d["p_new_step"]
+    for s in d["seeds"]:
+        s = int(s)
+        psrs.reset_sampler(seed=s)
+        want_rows, want_resets = d[f"s{s}_step_rows"], d[f"s{s}_step_reset_z"]
+        rows, resets = [], []
+        obs = psrs.reset()
+        resets.append(-2 if obs is None else int(psrs._impl.z))
+        assert obs.shape == (4,) and obs.dtype == np.float32
+        while obs is not None:
+            dist = torch.distributions.Categorical(probs=torch.from_numpy(p_new)) if len(rows) % 2 else p_new
+            out = psrs.step_dist(dist)
+            assert len(out) == (6 if new_api else 5)
+            if out[0] is None:
+                assert all(x is None for x in out)  # per_state_rejection.py:93-94
+                rows.append(-1)
+                break
+            row = psrs._impl._env.last_row
+            rows.append(row)
+            action, obs, reward, done, info = out[0], out[1], out[2], out[3], out[-1]
+            if new_api:
+                assert out[4] is False
+            assert action == e["actions"][row] and np.array_equal(obs, e["next_observations"][row])
+            assert reward == e["rewards"][row] and done == bool(e["terminals"][row])
+            assert info["z"] == d["in_z"][row] and np.array_equal(info["p"], e["action_distributions"][row])
+            if done:
+                obs = psrs.reset()
+                resets.append(-2 if obs is None else int(psrs._impl.z))
+        assert np.array_equal(rows, want_rows)
+        assert np.array_equal(resets, want_resets)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a4 / f4: offsim_step_batch with R > 1
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("f32", [False, True], ids=["f64", "f32"])
+def test_step_batch_many_rollouts_vs_oracle(f32, gpu):
+    """BatchedPSRS.step with R = 33 rollouts, a different random p_new per rollout and per call (some with zeros), in f64 and in
+    the all-float32 arithmetic of NumPy promotion, a third of the rollouts never reset (inactive) -- against 33
+    oracle environments stepped one call at a time (psrs.py:39-57)."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    N, nS, nA, R = 6000, 25, 5, 33
+    e = synth.synth_iid(N, nS, nA, seed=77)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(table, R)
+    seeds = [500 + 3 * i for i in range(R)]
+    env.reset_sampler(seeds)
+    active = np.array([i % 3 != 2 for i in range(R)])
+    first = env.reset(mask=torch.from_numpy(active).to(gpu)).cpu().numpy()
+    base = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    oras = [base.clone() for _ in range(R)]
+    for i, s in enumerate(seeds):
+        oras[i].reset_sampler(s)
+        if active[i]:
+            assert first[i] == oras[i].reset()
+    g = np.random.default_rng(9)
+    alive = active.copy()
+    n_calls = 0
+    while alive.any() and n_calls < 400:
+        p = g.dirichlet(np.ones(nA), R)
+        p[g.random((R, nA)) < 0.1] = 0.0  # zeros: inf / nan ratios (nan => accept)
+        p = p.astype(np.float32) if f32 else p
+        row, status, popped = (x.cpu().numpy() for x in env.step(p))
+        for i in range(R):
+            if not active[i]:
+                assert status[i] == L.ST_INACTIVE and row[i] == -1
+                continue
+            if not alive[i]:
+                continue
+            ref_row, ref_pop = oras[i].step(p[i].astype(np.float64), prob_dtype=O.PROB_F32 if f32 else O.PROB_F64)
+            assert popped[i] == ref_pop, (n_calls, i)
+            if ref_row is None:
+                assert status[i] == L.ST_EXHAUSTED and row[i] == -1
+                alive[i] = False
+            else:
+                assert status[i] == L.ST_OK and row[i] == ref_row, (n_calls, i)
+        n_calls += 1
+    assert n_calls > 50 and not alive.any()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the headline kernel instance on a headline-size table
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_headline_table_size_against_oracle(gpu):
+    """10 M transitions x 64 rollouts, no trace outputs: the template instance and segment sizes (61.7 k rows per state) that
+    bench.py times at 4096 rollouts.  Two seeds against the oracle (accepted steps, candidates, episodes, value estimate
+    within 1e-5, sum of returns to 1e-9 relative); all 64 through the size-independent properties."""
+    import threading
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    N, nS, nA, R = 10_000_000, 162, 2, 64
+    e = synth.synth_iid(N, nS, nA, seed=20221107)
+    pi = synth.dirichlet_policy(nS, nA)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(table, R)
+    seeds = list(range(R - 1)) + [0]
+    pi_slots = table.policy_slots(pi)
+    env.reset_sampler(seeds, policy=pi_slots)
+    o = env.eval_mc(pi_slots, 0.99)
+    torch.cuda.synchronize()
+    steps, cand = o["steps"].cpu().numpy(), o["cand"].cpu().numpy()
+    cur = env.state.cursor.cpu().numpy().astype(np.int64)
+    seg = table.seg_off.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (cur <= np.diff(seg)[None, :]).all() and cur.sum(axis=1).tolist() == cand.tolist()
+    assert steps[0] == steps[-1] and float(o["sum_g"][0]) == float(o["sum_g"][-1])  # same seed, same result
+    assert (o["status"].cpu().numpy() == 1).all()
+    base = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    res = {}
+
+    def work(s):
+        c = base.clone()
+        c.reset_sampler(s)
+        res[s] = c.evalmc(10 ** 9, pi, 0.99)
+
+    th = [threading.Thread(target=work, args=(s,)) for s in (0, 41)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for s in (0, 41):
+        ref = res[s]
+        assert int(steps[s]) == ref["steps"] and int(cand[s]) == ref["candidates"]
+        assert int(o["n_ep"][s]) == len(ref["Gs"]) and int(o["n_len"][s]) == len(ref["lengths"])
+        assert abs(float(o["sum_g"][s]) - ref["Gs"].sum()) <= 1e-9 * abs(ref["Gs"].sum())
+        assert abs(float(o["sum_g"][s]) / len(ref["Gs"]) - ref["Gs"].mean()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# e: two ranks of the HIP path into the all-reduce
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_path):
+    """One rank: its episode-disjoint shard of the log through BatchedPSRS on the GPU, then the all-reduce of [R,2]."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.distributed import allreduce_estimates, shard_episodes, shard_rollouts
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    torch.cuda.set_device(0)  # both ranks share the box's one GPU: gloo carries the collective (RCCL needs one GPU per rank)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    e = synth.synth_iid(60_000, 25, 5, seed=4)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = np.arange(12, dtype=np.uint64)
+
+    def evaluate(mask, sd):
+        t = TransitionTable(e["z"][mask], e["actions"][mask], e["rewards"][mask], e["z_next"][mask], e["terminals"][mask],
+                            e["action_distributions"][mask], (e["steps"] == 0)[mask], device=dev)
+        env = BatchedPSRS(t, len(sd))
+        env.reset_sampler(sd)
+        o = env.eval_mc(t.policy_slots(pi), 0.99)
+        return torch.stack([o["sum_g"], o["n_ep"].to(torch.float64)], dim=1)
+
+    # (1) log sharded by episode, every seed on every shard
+    est = evaluate(shard_episodes(e["episode_ids"], rank, world), seeds).cpu()
+    mine = est.clone()
+    allreduce_estimates(est)
+    # (2) rollouts sharded, table replicated
+    lo, hi = shard_rollouts(len(seeds), rank, world)
+    full = torch.zeros((len(seeds), 2), dtype=torch.float64)
+    full[lo:hi] = evaluate(np.ones(len(e["z"]), bool), seeds[lo:hi]).cpu()
+    allreduce_estimates(full)
+    np.savez(out_path + f".{rank}.npz", est=est.numpy(), mine=mine.numpy(), full=full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_of_the_hip_path_feed_the_allreduce(tmp_path, gpu):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.distributed import shard_episodes
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    world = 2
+    out = str(tmp_path / "rank")
+    mp.spawn(_rank_main, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = [np.load(out + f".{r}.npz") for r in range(world)]
+    assert np.array_equal(got[0]["est"], got[1]["est"]) and np.array_equal(got[0]["full"], got[1]["full"])
+    assert np.array_equal(got[0]["est"], got[0]["mine"] + got[1]["mine"])  # SUM of two f64 addends: exact
+    # the same shards evaluated by this (single) process: what each rank contributed
+    e = synth.synth_iid(60_000, 25, 5, seed=4)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = np.arange(12, dtype=np.uint64)
+    t0 = e["steps"] == 0
+    masks = [shard_episodes(e["episode_ids"], r, world) for r in range(world)]
+    for r, m in enumerate(masks):
+        t = TransitionTable(e["z"][m], e["actions"][m], e["rewards"][m], e["z_next"][m], e["terminals"][m],
+                            e["action_distributions"][m], t0[m], device=gpu)
+        env = BatchedPSRS(t, len(seeds))
+        env.reset_sampler(seeds)
+        o = env.eval_mc(t.policy_slots(pi), 0.99)
+        assert np.array_equal(got[r]["mine"][:, 0], o["sum_g"].cpu().numpy()) and np.array_equal(got[r]["mine"][:, 1], o["n_ep"].cpu().numpy())
+    # two seeds against the oracle, shard by shard, combined the same way (sum of sums / sum of counts)
+    for k in (0, 7):
+        tot = np.zeros(2)
+        for m in masks:
+            ora = O.OraclePSRS(e["z"][m], e["actions"][m], e["rewards"][m], e["z_next"][m], e["terminals"][m], e["action_distributions"][m], t0[m])
+            ora.reset_sampler(int(seeds[k]))
+            ref = ora.evalmc(10 ** 9, pi, 0.99)
+            tot += (ref["Gs"].sum(), len(ref["Gs"]))
+        assert got[0]["est"][k, 1] == tot[1]
+        assert abs(got[0]["est"][k, 0] / got[0]["est"][k, 1] - tot[0] / tot[1]) <= 1e-5
+    # rollout-sharded: the assembled table equals one process running all seeds on the whole log
+    t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(t, len(seeds))
+    env.reset_sampler(seeds)
+    o = env.eval_mc(t.policy_slots(pi), 0.99)
+    assert np.array_equal(got[0]["full"][:, 0], o["sum_g"].cpu().numpy()) and np.array_equal(got[0]["full"][:, 1], o["n_ep"].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1: sparse / hashed state ids and out-of-range actions (the reference keys a dict by z and indexes p with a)
+# ---------------------------------------------------------------------------------------------------
+def test_sparse_state_ids_and_action_range(gpu):
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(5000, 25, 3, seed=12)
+    ids = np.sort(np.random.default_rng(1).choice(2 ** 40, 25, replace=False)).astype(np.int64) - 2 ** 39  # hashed ids, some negative
+    z, zn = ids[e["z"]], ids[e["z_next"]]
+    t0 = e["steps"] == 0
+    table = TransitionTable(z, e["actions"], e["rewards"], zn, e["terminals"], e["action_distributions"], t0, device=gpu)
+    assert table.n_slots == 25 and table.z_base is None and np.array_equal(table.slot_z, ids)
+    assert table.slot_of(ids[7]) == 7 and table.slot_of(12345) == -1 and table.z_of(24) == ids[24]
+    dense = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    pi = synth.dirichlet_policy(25, 3)
+    outs = []
+    for t in (table, dense):  # ranks of the ids == the dense ids: identical queues, identical rollouts
+        env = BatchedPSRS(t, 4)
+        env.reset_sampler([0, 1, 2, 3])
+        outs.append(env.eval_mc(pi, 0.9, trace_cap=5000))
+    for k in ("steps", "cand", "sum_g", "trace_row"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    ora = O.OraclePSRS(z, e["actions"], e["rewards"], zn, e["terminals"], e["action_distributions"], t0)
+    ora.reset_sampler(2)
+    pi_by_rank = {int(i): pi[k] for k, i in enumerate(ids)}
+    row = ora.reset()
+    assert row is not None
+    n = 0
+    while True:
+        r, _ = ora.step(pi_by_rank[ora.cur_z])
+        if r is None:
+            break
+        assert int(outs[0]["trace_row"][2, n]) == r
+        n += 1
+        if e["terminals"][r] and ora.reset() is None:
+            break
+    assert n > 100
+    a_bad = e["actions"].copy()
+    a_bad[17] = 3
+    with pytest.raises(IndexError):
+        TransitionTable(e["z"], a_bad, e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    a_neg = e["actions"].copy()
+    a_neg[e["actions"] == 2] = -1  # NumPy: p[-1] is the last column
+    wrapped = TransitionTable(e["z"], a_neg, e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    assert torch.equal(wrapped.a, dense.a)
