@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PARITY_SEEDS = (0, 1, 2047, 4095)
+_REAL_STDOUT = sys.stdout
 
 
 def parse():
@@ -431,7 +432,8 @@ def run(a):
                 raise SystemExit("bench.py: the GPU results differ from the oracle on this table -- no number is reported")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(base or oracle_for(e), pi, a.gamma, a.cpu_sample_seconds, a.cpu_threads_cap)
-        print(json.dumps(out), flush=True)
+        _REAL_STDOUT.write(json.dumps(out) + "\n")
+        _REAL_STDOUT.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -445,6 +447,11 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1:
         return spawn_ranks(a)  # before any GPU call in this process
+    # stdout carries exactly one JSON line: whatever libraries print there (gloo's connection banner, ...) goes to stderr
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if env_world is not None and int(env_world) != a.gpus:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}; start one rank per GPU (or leave WORLD_SIZE unset and let "
                          "bench.py start them)\n")

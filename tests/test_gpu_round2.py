@@ -93,7 +93,7 @@ def test_step_batch_many_rollouts_vs_oracle(f32, gpu):
     from rl_offline_simulation_amd import synth, _lib as L
     from rl_offline_simulation_amd.table import TransitionTable
     from rl_offline_simulation_amd.evaluators import BatchedPSRS
-    N, nS, nA, R = 6000, 25, 5, 33
+    N, nS, nA, R = 1500, 25, 5, 33
     e = synth.synth_iid(N, nS, nA, seed=77)
     t0 = e["steps"] == 0
     table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
@@ -111,7 +111,7 @@ def test_step_batch_many_rollouts_vs_oracle(f32, gpu):
     g = np.random.default_rng(9)
     alive = active.copy()
     n_calls = 0
-    while alive.any() and n_calls < 400:
+    while alive.any() and n_calls < 5000:
         p = g.dirichlet(np.ones(nA), R)
         p[g.random((R, nA)) < 0.1] = 0.0  # zeros: inf / nan ratios (nan => accept)
         p = p.astype(np.float32) if f32 else p
