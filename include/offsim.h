@@ -226,6 +226,35 @@ int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64
                         const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
                         void *stream);
 
+/* ---- headline scan on per-rollout candidate streams ------------------------------------------------------------
+ * For a fixed tabular policy the scan needs, per candidate, only the 32-bit digest of its compiled key (top 21 bits of
+ * the threshold T, done, z_next) -- and per ACCEPTED candidate the row (for its reward).  Gathering digests through a
+ * per-rollout permutation moves a 64-byte sector per 4-byte digest, so the sampler reset can instead lay the queue
+ * orders out as two streams per rollout, both indexed like `perm` (seg_off[s] + k = k-th element of state s's queue):
+ *   dig [n, N] u32   digest of the candidate at that queue position      -> read sequentially by the scan
+ *   loc [n, N] u16   its row inside the state's segment (grouped row - seg_off[s]); needs segments <= 65536 rows
+ * offsim_compile_digests: dig32[g] = high dword of the compiled key of grouped row g (offsim_compile_policy's keys).
+ * offsim_shuffle_queues_keys: PSRS.reset_sampler's shuffles (psrs.py:22-23,29-30; same orders as offsim_shuffle_queues,
+ *   bit for bit) written as those streams; init_perm_out as in offsim_shuffle_queues.  OFFSIM_EUNSUPPORTED if a state
+ *   has more than 65536 rows (use offsim_shuffle_queues + offsim_eval_mc_keys).
+ * offsim_eval_mc_streams: evalMC_psrs (psrs.py:241-271) from the streams; same outputs, bit for bit, as offsim_eval_mc /
+ *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide 21-bit digest ties
+ *   exactly.  Strides are in elements; stride 0 = one order shared by all rollouts; loc == NULL = queues in table order
+ *   (dig = dig32 itself, stride 0).  ro->perm / perm_stride are ignored; ro->init_perm is used as everywhere else.
+ *   n_slots <= 256. */
+typedef struct offsim_streams {
+    const uint32_t *dig;
+    int64_t dig_stride;
+    const uint16_t *loc;
+    int64_t loc_stride;
+} offsim_streams;
+int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, uint32_t *dig32_out, void *stream);
+int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32,
+                               uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream);
+int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro, const offsim_streams *sm, const uint64_t *keys,
+                           double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
+                           const offsim_evalmc_out *out, void *stream);
+
 /* ---- encoders (a10, a11) --------------------------------------------------------------------- */
 
 /* CartpoleBoxEncoder.encode (offsim4rl/encoders/heuristic.py:19-71): obs [N,4] f32 -> z [N] i32 in -1..161 */

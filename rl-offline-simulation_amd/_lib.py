@@ -38,6 +38,11 @@ class EvalMCOut(C.Structure):
                 ("trace_cap", _i64), ("dbg", _vp)]
 
 
+class Streams(C.Structure):
+    """struct offsim_streams"""
+    _fields_ = [("dig", _vp), ("dig_stride", _i64), ("loc", _vp), ("loc_stride", _i64)]
+
+
 class TD(C.Structure):
     """struct offsim_td"""
     _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64)]
@@ -66,6 +71,10 @@ SIGNATURES = {
                                  C.POINTER(EvalMCOut), C.POINTER(TD), _vp]),
     "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
     "offsim_eval_mc_keys_kernel": (C.c_char_p, [_i32, _i32]),
+    "offsim_compile_digests": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
+    "offsim_shuffle_queues_keys": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "offsim_eval_mc_streams": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), C.POINTER(Streams), _vp, C.c_double, _vp, _i64, _i64,
+                                         C.POINTER(EvalMCOut), _vp]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),

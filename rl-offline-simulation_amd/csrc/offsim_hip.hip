@@ -222,162 +222,92 @@ extern "C" int offsim_seed_streams(const uint64_t *seeds, int32_t R, uint64_t *r
     return OFFSIM_OK;
 }
 
-__global__ void k_iota_rows(uint32_t *__restrict__ out, int64_t n_cols, int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) out[i] = (uint32_t)(i % n_cols);
-}
-
-// Fisher-Yates chains: one per (state, rollout), each restarting default_rng(seed) (psrs.py:29-30), plus one per
-// rollout for the init queue (psrs.py:22-23).  A chain is a strictly sequential walk of random 4-byte swaps over its
-// own segment; with ~660 k chains in flight the kernel is bound by random-sector HBM traffic, so the job is to move
-// as few sectors as possible:
-//  - lanes of a wavefront take the SAME state of consecutive rollouts: equal trip counts, no divergence;
-//  - the descending side x[i] is processed in 64-byte blocks held in registers (one 16-word load, 16 swap steps, one
-//    16-word store): without this the line of x[i] is evicted between two visits of its lane (the chip holds 0.5 M
-//    chains but only 32 MiB of L2) and refetched, ~50 B per swap of pure waste (rocprofv3 FETCH_SIZE);
-//  - the random side x[j] is one 64-B sector read and one written back per swap: that part is inherent.
-struct ShuffleBlock {
-    uint32_t v[16];
-};
-__device__ __forceinline__ uint32_t blk_get(const ShuffleBlock &b, uint32_t k) {
-    uint32_t r = b.v[0];
-#pragma unroll
-    for (int i = 1; i < 16; i++) r = (k == (uint32_t)i) ? b.v[i] : r;
-    return r;
-}
-__device__ __forceinline__ void blk_set(ShuffleBlock &b, uint32_t k, uint32_t val) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) b.v[i] = (k == (uint32_t)i) ? val : b.v[i];
-}
-
-__global__ void k_shuffle_queues(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0,
-                                 const uint64_t *__restrict__ seeds, int32_t n_perm, uint32_t *__restrict__ perm,
-                                 uint32_t *__restrict__ init_perm) {
-    const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_chains = (int64_t)(n_slots + 1) * n_perm;
-    if (chain >= n_chains) return;
-    const int32_t s = (int32_t)(chain / n_perm);
-    const int32_t r = (int32_t)(chain - (int64_t)s * n_perm);
-    uint32_t *x;
-    uint32_t n;
-    if (s < n_slots) {
-        const uint32_t b = seg_off[s];
-        n = seg_off[s + 1] - b;
-        x = perm + (int64_t)r * N + b;
-    } else {  // the init queue
-        n = (uint32_t)N0;
-        x = init_perm + (int64_t)r * N0;
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and sticks: set once per (kernel, device), not per launch
+// (it sits on the single-step latency path otherwise)
+static hipError_t allow_big_lds_fn(const void *fn, int bytes) {
+    struct Seen {
+        const void *fn;
+        int max_bytes;  // the limit applied on the devices in `devs` (only ever raised)
+        uint64_t devs;  // one bit per device id (ids >= 64 are set every time)
+    };
+    static thread_local Seen seen[64];
+    static thread_local int n_seen = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    Seen *hit = nullptr;
+    for (int i = 0; i < n_seen; i++)
+        if (seen[i].fn == fn) hit = &seen[i];
+    if (hit && dev < 64 && bytes <= hit->max_bytes && ((hit->devs >> dev) & 1ull)) return hipSuccess;
+    const int want = hit && hit->max_bytes > bytes ? hit->max_bytes : bytes;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    if (e != hipSuccess) return e;
+    if (!hit && n_seen < 64) {
+        hit = &seen[n_seen++];
+        hit->fn = fn;
+        hit->max_bytes = 0;
+        hit->devs = 0;
     }
-    if (n < 2) return;
-    PcgSeq g;
-    g.init(pcg_seed(seeds[r]));
-    // 64-byte alignment of the blocks is by ADDRESS, so that one block is exactly one sector
-    const uint32_t mis = (uint32_t)(((uintptr_t)x >> 2) & 15u);  // words by which x[0] is past a 64-B boundary
-    uint32_t i = n - 1;
-    // head: single steps down to the first index that is the top word of a sector ((i + mis) % 16 == 15) with the
-    // whole sector inside the chain's remaining range (i >= 16, so that its bottom index is >= 1)
-    while (i >= 1 && !((((i + mis) & 15u) == 15u) && i >= 16u)) {
-        const uint32_t j = g.interval32(i);
-        const uint32_t xi = x[i], xj = x[j];
-        x[i] = xj;
-        x[j] = xi;
-        i--;
-    }
-    // body: whole aligned blocks while the block bottom stays >= 1
-    while (i >= 16u) {
-        const uint32_t base = i - 15u;
-        ShuffleBlock blk;
-        const uint4 *src = (const uint4 *)(x + base);
-        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-        blk.v[0] = q0.x; blk.v[1] = q0.y; blk.v[2] = q0.z; blk.v[3] = q0.w;
-        blk.v[4] = q1.x; blk.v[5] = q1.y; blk.v[6] = q1.z; blk.v[7] = q1.w;
-        blk.v[8] = q2.x; blk.v[9] = q2.y; blk.v[10] = q2.z; blk.v[11] = q2.w;
-        blk.v[12] = q3.x; blk.v[13] = q3.y; blk.v[14] = q3.z; blk.v[15] = q3.w;
-#pragma unroll
-        for (int k = 15; k >= 0; k--) {
-            const uint32_t ii = base + (uint32_t)k;
-            const uint32_t j = g.interval32(ii);
-            if (j >= base) {  // the partner is inside the register block (p = 16/i): swap in registers
-                const uint32_t t = blk_get(blk, j - base);
-                blk_set(blk, j - base, blk.v[k]);
-                blk.v[k] = t;
-            } else {
-                const uint32_t xj = x[j];
-                x[j] = blk.v[k];
-                blk.v[k] = xj;
-            }
+    if (hit) {
+        if (want > hit->max_bytes) {
+            hit->max_bytes = want;
+            hit->devs = 0;
         }
-        uint4 *dst = (uint4 *)(x + base);
-        dst[0] = make_uint4(blk.v[0], blk.v[1], blk.v[2], blk.v[3]);
-        dst[1] = make_uint4(blk.v[4], blk.v[5], blk.v[6], blk.v[7]);
-        dst[2] = make_uint4(blk.v[8], blk.v[9], blk.v[10], blk.v[11]);
-        dst[3] = make_uint4(blk.v[12], blk.v[13], blk.v[14], blk.v[15]);
-        i = base - 1u;
+        if (dev < 64) hit->devs |= 1ull << dev;
     }
-    // tail: the last few positions
-    for (; i >= 1; i--) {
-        const uint32_t j = g.interval32(i);
-        const uint32_t xi = x[i], xj = x[j];
-        x[i] = xj;
-        x[j] = xi;
+    return hipSuccess;
+}
+#define allow_big_lds(kernel, bytes) allow_big_lds_fn((const void *)(kernel), (bytes))
+
+// wave-parallel exact Fisher-Yates (shuffle_wave.hpp), one workgroup per chain.  dig_out == NULL: orders as permutations of grouped
+// rows; otherwise the keyed form (digest stream + 16-bit local rows per queue position) for the state queues
+static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
+                          const uint32_t *dig32, uint32_t *dig_out, uint16_t *loc_out, hipStream_t st) {
+    const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
+    const uint32_t min_seg = t->min_seg > 0 ? (uint32_t)(t->min_seg > 0xffffffffll ? 0xffffffffll : t->min_seg) : 1u;
+    const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
+    const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
+    if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
+    HIP_TRY(allow_big_lds(k_shuffle_wave<true>, 160 * 1024));
+    if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
+        hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(), st, t->seg_off, t->n_slots, t->N,
+                           t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
+        LAUNCH_CHECK();
     }
+    // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
+    // chains share a CU instead of inheriting the one-chain-per-CU occupancy of a 60 k-row segment
+    static const uint32_t bounds[] = {SHUF_CAP16, 32768u, 8192u, 2048u, 0u};
+    for (int k = 0; k < 4; k++) {
+        const uint32_t hi = bounds[k], lo = bounds[k + 1];
+        const bool seg_in = min_seg <= hi && max_seg > lo, init_in = n0 > lo && n0 <= hi;
+        if (!seg_in && !init_in) continue;
+        uint32_t need = 0;
+        if (seg_in) need = max_seg < hi ? max_seg : hi;
+        if (init_in && n0 > need) need = n0;
+        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
+        hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
+                           n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
+        LAUNCH_CHECK();
+    }
+    return OFFSIM_OK;
 }
 
 extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out,
                                      uint32_t *init_perm_out, void *stream) {
     if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");
     if (n_perm == 0) return OFFSIM_OK;
-    hipStream_t st = (hipStream_t)stream;
-    static const bool legacy = getenv("OFFSIM_SHUFFLE_LEGACY") != nullptr;  // the one-lane-per-chain kernel (A/B measurements only)
-    if (!legacy) {
-        // wave-parallel exact Fisher-Yates (shuffle_wave.hpp): one workgroup per chain
-        const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
-        const uint32_t min_seg = t->min_seg > 0 ? (uint32_t)(t->min_seg > 0xffffffffll ? 0xffffffffll : t->min_seg) : 1u;
-        const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
-        const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
-        if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
-        HIP_TRY(hipFuncSetAttribute((const void *)k_shuffle_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  // (per device)
-        if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
-            hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(), st, t->seg_off, t->n_slots, t->N,
-                               t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu);
-            LAUNCH_CHECK();
-        }
-        // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
-        // chains share a CU instead of inheriting the one-chain-per-CU occupancy of a 60 k-row segment
-        static const uint32_t bounds[] = {SHUF_CAP16, 32768u, 8192u, 2048u, 0u};
-        for (int k = 0; k < 4; k++) {
-            const uint32_t hi = bounds[k], lo = bounds[k + 1];
-            const bool seg_in = min_seg <= hi && max_seg > lo, init_in = n0 > lo && n0 <= hi;
-            if (!seg_in && !init_in) continue;
-            uint32_t need = 0;
-            if (seg_in) need = max_seg < hi ? max_seg : hi;
-            if (init_in && n0 > need) need = n0;
-            const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
-            hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
-                               n_perm, perm_out, init_perm_out, lo, hi);
-            LAUNCH_CHECK();
-        }
-        return OFFSIM_OK;
-    }
-    // start from table order: perm[r][g] = g, init_perm[r][k] = k
-    if (t->N > 0) {
-        int64_t total = t->N * n_perm;
-        unsigned nb = (unsigned)((total + 1023) / 1024 > 16384 ? 16384 : (total + 1023) / 1024);
-        hipLaunchKernelGGL(k_iota_rows, dim3(nb), dim3(256), 0, st, perm_out, t->N, total);
-        LAUNCH_CHECK();
-    }
-    if (t->N0 > 0) {
-        int64_t total = t->N0 * n_perm;
-        unsigned nb = (unsigned)((total + 1023) / 1024 > 16384 ? 16384 : (total + 1023) / 1024);
-        hipLaunchKernelGGL(k_iota_rows, dim3(nb), dim3(256), 0, st, init_perm_out, t->N0, total);
-        LAUNCH_CHECK();
-    }
-    const int64_t n_chains = (int64_t)(t->n_slots + 1) * n_perm;
-    hipLaunchKernelGGL(k_shuffle_queues, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
-                       n_perm, perm_out, init_perm_out);
-    LAUNCH_CHECK();
-    return OFFSIM_OK;
+    return launch_shuffle(t, seeds, n_perm, perm_out, init_perm_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32,
+                                          uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream) {
+    if (!t || !seeds || n_perm < 0 || !init_perm_out || (t->N > 0 && (!dig32 || !dig_out || !loc_out)))
+        return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad argument%s");
+    if (t->max_seg <= 0 && t->N > 0) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: offsim_table.max_seg must be set%s");
+    if (t->max_seg > (int64_t)SHUF_CAP16)
+        return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows (16-bit local rows); use offsim_shuffle_queues%s");
+    if (n_perm == 0) return OFFSIM_OK;
+    return launch_shuffle(t, seeds, n_perm, nullptr, init_perm_out, dig32, dig_out, loc_out, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +746,7 @@ extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const 
 #define LAUNCH_MC(PL, PROB)                                                                                          \
     do {                                                                                                             \
         if (lds > 64 * 1024)                                                                                         \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, PROB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIP_TRY(allow_big_lds((k_eval_mc<PL, PROB, false>), (int)lds)); \
         hipLaunchKernelGGL((k_eval_mc<PL, PROB, false>), grid, block, lds, st, *t, *ro, (const PROB *)pi, reject_mode, gamma, \
                            gamma_pow, n_gamma_pow, max_episodes, *out, offsim_td{});                                 \
     } while (0)
@@ -969,7 +899,7 @@ extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const 
 #define LAUNCH_TD(PL)                                                                                                   \
     do {                                                                                                                \
         if (lds > 64 * 1024)                                                                                            \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc<PL, double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIP_TRY(allow_big_lds((k_eval_mc<PL, double, true>), (int)lds)); \
         hipLaunchKernelGGL((k_eval_mc<PL, double, true>), grid, block, lds, st, *t, *ro, pi, reject_mode, gamma, gamma_pow, \
                            n_gamma_pow, max_episodes, *out, *td);                                                       \
     } while (0)
@@ -1054,11 +984,11 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
         const size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) + 4 * region;                   \
         dim3 grid2((ro->R + 3) / 4), block2(512);                                                                     \
         if (trace) {                                                                                                  \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc_split<W, ROUNDS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIP_TRY(allow_big_lds((k_eval_mc_split<W, ROUNDS, true>), 160 * 1024)); \
             hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, true>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \
         } else {                                                                                                      \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_eval_mc_split<W, ROUNDS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIP_TRY(allow_big_lds((k_eval_mc_split<W, ROUNDS, false>), 160 * 1024)); \
             hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, false>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \
         }                                                                                                             \
@@ -1076,6 +1006,61 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     else if (rounds == 3) LAUNCH_WIN(8, 3);
     else LAUNCH_WIN(8, 4);
 #undef LAUNCH_WIN
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Headline scan on per-rollout candidate streams (scan_rows.hpp)
+// ------------------------------------------------------------------------------------------------
+#include "scan_rows.hpp"
+
+__global__ void k_key_digests(const uint64_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < N) out[g] = (uint32_t)(keys[g] >> 32);
+}
+extern "C" int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, uint32_t *dig32_out, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (t->N > 0 && (!keys || !dig32_out)) return fail(OFFSIM_EINVAL, "compile_digests: bad argument%s");
+    if (t->N == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_key_digests, dim3((unsigned)((t->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, t->N, dig32_out);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro, const offsim_streams *sm, const uint64_t *keys,
+                                      double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
+                                      const offsim_evalmc_out *out, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !out || !sm || (t->N > 0 && (!keys || !sm->dig))) return fail(OFFSIM_EINVAL, "eval_mc_streams: bad argument%s");
+    if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
+        return fail(OFFSIM_EINVAL, "eval_mc_streams: required output is NULL%s");
+    if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: candidate windows support at most 256 states%s");
+    if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
+    if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
+    if (ro->R == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool trace = out->trace_row || out->trace_pop;
+    // four rollouts per wavefront; as many wavefronts per workgroup (<= 4) as the CU's 160 KiB of LDS hold regions for
+    const uint32_t region = rows_region_bytes((uint32_t)t->n_slots);
+    const uint32_t seg_bytes = (((uint32_t)t->n_slots + 1u) * 4u + 511u) & ~511u;
+    int waves = (int)((160u * 1024u - 512u - seg_bytes) / (4u * region));
+    waves = waves > 4 ? 4 : waves;
+    if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
+    const int rpb = waves * 4;
+    const size_t lds = 512 + seg_bytes + (size_t)rpb * region;
+    dim3 grid((unsigned)((ro->R + rpb - 1) / rpb)), block((unsigned)(waves * 64));
+    if (trace) {
+        HIP_TRY(allow_big_lds(k_eval_mc_rows<true>, 160 * 1024));
+        hipLaunchKernelGGL(k_eval_mc_rows<true>, grid, block, lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, n_gamma_pow, max_episodes, *out,
+                           seg_bytes, region);
+    } else {
+        HIP_TRY(allow_big_lds(k_eval_mc_rows<false>, 160 * 1024));
+        hipLaunchKernelGGL(k_eval_mc_rows<false>, grid, block, lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, n_gamma_pow, max_episodes, *out,
+                           seg_bytes, region);
+    }
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }
@@ -1176,7 +1161,7 @@ static int launch_mlp_mfma(const XT *x, int64_t N, int dO, const float *W1, cons
 #define LAUNCH_MFMA(HTc, ZTc)                                                                                              \
     do {                                                                                                                   \
         if (lds > 64 * 1024)                                                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp_mfma<XT, HTc, ZTc>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIP_TRY(allow_big_lds((k_encode_mlp_mfma<XT, HTc, ZTc>), (int)lds)); \
         hipLaunchKernelGGL((k_encode_mlp_mfma<XT, HTc, ZTc>), dim3(nb), dim3(256), lds, st, x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits); \
     } while (0)
     if (HT == 1 && ZT == 1) LAUNCH_MFMA(1, 1);
@@ -1209,10 +1194,10 @@ extern "C" int offsim_encode_mlp(const void *x, int32_t x_dtype, int64_t N, int3
     if (nb > 2048) nb = 2048;
     hipStream_t st = (hipStream_t)stream;
     if (x_dtype == OFFSIM_F32) {
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) HIP_TRY(allow_big_lds((k_encode_mlp<float>), (int)lds));
         hipLaunchKernelGGL(k_encode_mlp<float>, dim3(nb), dim3(256), lds, st, (const float *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits);
     } else if (x_dtype == OFFSIM_F16) {
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k_encode_mlp<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) HIP_TRY(allow_big_lds((k_encode_mlp<__half>), (int)lds));
         hipLaunchKernelGGL(k_encode_mlp<__half>, dim3(nb), dim3(256), lds, st, (const __half *)x, N, dO, W1, b1, H, W2, b2, nZ, out_z, out_logits);
     } else return fail(OFFSIM_EINVAL, "encode_mlp: x_dtype must be OFFSIM_F32 or OFFSIM_F16%s");
     LAUNCH_CHECK();

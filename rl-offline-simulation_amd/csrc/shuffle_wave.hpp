@@ -59,7 +59,8 @@ constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_SQ
 template <bool LDS16>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
-                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi) {
+                   int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi,
+                   const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
@@ -309,12 +310,48 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    if (LDS16) {  // the only HBM traffic of the chain: one coalesced write of the finished permutation
+    if (LDS16) {  // the only HBM traffic of the chain: one coalesced write of the finished order
         __attribute__((address_space(3))) const uint32_t *xw = (__attribute__((address_space(3))) const uint32_t *)x16;
-        for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) {
-            const uint32_t two = xw[k];
-            xg[2u * k] = base_val + (two & 0xffffu);
-            if (2u * k + 1u < n) xg[2u * k + 1u] = base_val + (two >> 16);
+        if (dig_out && s < n_slots) {
+            // keyed form (offsim_shuffle_queues_keys): the queue order as the scan wants to read it -- the digest of the
+            // candidate at every queue position (gathered from this segment's slice of dig32: L2-resident, the same few
+            // hundred KB for every rollout's chain of this state) and its 16-bit row inside the segment
+            const uint32_t *dsrc = dig32 + base_val;
+            uint32_t *dg = dig_out + (int64_t)r * N + base_val;
+            uint16_t *lc = loc_out + (int64_t)r * N + base_val;
+            const uint32_t pairs = (n + 1u) >> 1;
+            for (uint32_t k0 = threadIdx.x; k0 < pairs; k0 += 1024u) {  // four pairs per thread in flight
+                uint32_t two[4], d0[4], d1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u;
+                    two[u] = k < pairs ? xw[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i1 = two[u] >> 16;  // (the slot behind an odd-length segment still holds its identity value n)
+                    d0[u] = dsrc[two[u] & 0xffffu];
+                    d1[u] = dsrc[i1 < n ? i1 : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u;
+                    if (k < pairs) {
+                        dg[2u * k] = d0[u];
+                        lc[2u * k] = (uint16_t)(two[u] & 0xffffu);
+                        if (2u * k + 1u < n) {
+                            dg[2u * k + 1u] = d1[u];
+                            lc[2u * k + 1u] = (uint16_t)(two[u] >> 16);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) {
+                const uint32_t two = xw[k];
+                xg[2u * k] = base_val + (two & 0xffffu);
+                if (2u * k + 1u < n) xg[2u * k + 1u] = base_val + (two >> 16);
+            }
         }
     }
 }

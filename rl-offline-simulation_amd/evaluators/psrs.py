@@ -63,31 +63,122 @@ class BatchedPSRS:
         self._popped = torch.empty(R, dtype=torch.int32, device=dev)
         self._perm_buf = None
         self._init_perm_buf = None
+        self._dig_buf = self._loc_buf = None
+        self._streams = None
+        self._perm_lazy = None
+        self._pk_cache = None
+        self._dig32 = None
 
     # -- PSRS.reset_sampler (psrs.py:19-30) for all rollouts --
     def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None):
-        """`policy` (optional, [n_slots,nA]): the tabular policy the following eval_mc calls will evaluate.  It changes no
-        result; it lets the sampler reset lay the queue orders out for that evaluation."""
+        """`policy` (optional, [n_slots,nA] f64): the tabular policy the following eval_mc calls will evaluate.  It changes no
+        result; it lets the sampler reset write the queue orders as the candidate streams the row-packed scan reads
+        sequentially (offsim_shuffle_queues_keys: digest + 16-bit local row per queue position) instead of as permutations."""
         t, dev = self.table, self.table.device
         sd = seeds_tensor(seeds, dev)
         assert sd.numel() == self.R, "one seed per rollout"
         seed_streams(sd, self.state.rng)
         self.state.rewind()
+        self._streams = None
+        self._perm_lazy = None
+        keyed = policy is not None and self._streams_apply(policy)
         if shuffle == SHUFFLE_PER_ROLLOUT:
-            if self._perm_buf is None or self._perm_buf.shape[0] != self.R:
-                self._perm_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
+            if self._init_perm_buf is None or self._init_perm_buf.shape[0] != self.R:
                 self._init_perm_buf = torch.empty((self.R, max(t.N0, 1)), dtype=torch.int32, device=dev)
-            shuffle_queues(t, sd, self._perm_buf, self._init_perm_buf)
-            self.state.set_orders(self._perm_buf, t.N, self._init_perm_buf, t.N0)
+            if keyed:
+                self._perm_buf = None  # (the two forms of the orders are not kept side by side: 4 + 6 bytes per entry and rollout)
+                if self._dig_buf is None or self._dig_buf.shape[0] != self.R:
+                    self._dig_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
+                    self._loc_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int16, device=dev)
+                keys, dig32 = self._policy_keys(policy)
+                L.check(L.load().offsim_shuffle_queues_keys(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), L.ptr(self._dig_buf),
+                                                            L.ptr(self._loc_buf), L.ptr(self._init_perm_buf), L.stream_ptr()))
+                self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=self._policy_key(policy))
+                self.state.set_orders(None, 0, self._init_perm_buf, t.N0)
+                self._perm_lazy = "streams"
+            else:
+                self._dig_buf = self._loc_buf = None
+                if self._perm_buf is None or self._perm_buf.shape[0] != self.R:
+                    self._perm_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
+                shuffle_queues(t, sd, self._perm_buf, self._init_perm_buf)
+                self.state.set_orders(self._perm_buf, t.N, self._init_perm_buf, t.N0)
         elif shuffle == SHUFFLE_SHARED:
             assert shuffle_seed is not None
             perm, init_perm = shuffle_queues(t, seeds_tensor([shuffle_seed], dev))
             self._perm_buf, self._init_perm_buf = perm, init_perm
             self.state.set_orders(perm, 0, init_perm, 0)
+            if keyed:  # one shared order: the streams are one row, built from the permutation
+                keys, dig32 = self._policy_keys(policy)
+                p = perm[0, :t.N].to(torch.int64) & 0xFFFFFFFF
+                self._streams = dict(dig=dig32[p].contiguous(), dig_stride=0, loc=(p - self._seg_base()).to(torch.int16).contiguous(),
+                                     loc_stride=0, key=self._policy_key(policy))
         elif shuffle == SHUFFLE_NONE:
             self.state.set_orders(None, 0, None, 0)
+            if keyed:
+                keys, dig32 = self._policy_keys(policy)
+                self._streams = dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=self._policy_key(policy))
         else:
             raise ValueError(shuffle)
+
+    # ---- candidate streams for the row-packed scan ----
+    def _streams_apply(self, policy):
+        """The streams exist for what offsim_eval_mc_streams covers: f64 probabilities, the default reject rule, <= 256 states,
+        segments <= 65536 rows (16-bit local rows)."""
+        t = self.table
+        p = policy if isinstance(policy, torch.Tensor) else np.asarray(policy)
+        f64 = p.dtype in (torch.float64, np.float64, np.dtype(np.float64))
+        return (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= 65536 and t.N < 2 ** 32 - 1
+                and os.environ.get("OFFSIM_SCAN_ROWS", "1") != "0")
+
+    @staticmethod
+    def _policy_key(policy):
+        p = policy.detach().cpu().numpy() if isinstance(policy, torch.Tensor) else np.asarray(policy)
+        return (p.shape, p.dtype.str, hash(np.ascontiguousarray(p).tobytes()))
+
+    def _policy_keys(self, policy):
+        """(compiled 64-bit keys, their 32-bit digests) of `policy` on the device, cached per policy."""
+        k = self._policy_key(policy)
+        if getattr(self, "_pk_cache", None) is None or self._pk_cache[0] != k:
+            t = self.table
+            pi_d = torch.as_tensor(np.ascontiguousarray(policy) if not isinstance(policy, torch.Tensor) else policy,
+                                   dtype=torch.float64).to(t.device).reshape(t.n_slots, t.nA).contiguous()
+            keys = self.compile_policy(pi_d)
+            if getattr(self, "_dig32", None) is None:
+                self._dig32 = torch.empty(max(t.N, 1), dtype=torch.int32, device=t.device)
+            L.check(L.load().offsim_compile_digests(C.byref(t.c), L.ptr(keys), L.ptr(self._dig32), L.stream_ptr()))
+            self._pk_cache = (k, keys, self._dig32)
+        return self._pk_cache[1], self._pk_cache[2]
+
+    def _derive_streams(self, policy, max_entries=1 << 26):
+        """Candidate streams from queue orders that exist as permutations (reset_sampler without `policy`): one gather, done
+        for jobs of up to `max_entries` queue positions; bigger jobs pass `policy` to reset_sampler or run the window kernels."""
+        t, st = self.table, self.state
+        if not self._streams_apply(policy) or (st.perm is None and self._perm_lazy == "streams"):
+            return
+        n_rows = 1 if (st.perm is None or st.perm_stride == 0) else self.R
+        if n_rows * t.N > max_entries:
+            return
+        keys, dig32 = self._policy_keys(policy)
+        key = self._policy_key(policy)
+        if st.perm is None:  # table order
+            self._streams = dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=key)
+            return
+        p = st.perm.reshape(n_rows, -1)[:, :t.N].to(torch.int64) & 0xFFFFFFFF
+        self._streams = dict(dig=dig32[p].contiguous(), dig_stride=t.N if n_rows > 1 else 0,
+                             loc=(p - self._seg_base()[None, :]).to(torch.int16).contiguous(), loc_stride=t.N if n_rows > 1 else 0, key=key)
+
+    def _seg_base(self):
+        """seg_off of the state every grouped position belongs to ([N] int64)."""
+        t = self.table
+        so = (t.seg_off.to(torch.int64) & 0xFFFFFFFF)
+        return torch.repeat_interleave(so[:-1], so[1:] - so[:-1])
+
+    @property
+    def perm(self):
+        """Queue orders as permutations of grouped rows [R or 1, N] (built from the streams when the reset wrote those)."""
+        if self.state.perm is not None or self._perm_lazy != "streams":
+            return self.state.perm
+        return ((self._loc_buf.to(torch.int64) & 0xFFFF) + self._seg_base()[None, :]).to(torch.int32)
 
     def set_rejection_seeds(self, seeds):
         """Replace only the rejection streams (env.rejection_sampling_rng = default_rng(seed), psrs.py:20)."""
@@ -177,12 +268,26 @@ class BatchedPSRS:
             fast = can_fast
         if fast and not can_fast:
             raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule and <= 256 states")
-        if fast:
+        if fast and not (self._streams is not None and self._streams["key"] == self._policy_key(pi_slots)):
+            self._derive_streams(pi_slots)  # small jobs: the streams are gathered from the permutations on the spot
+        rows = bool(fast) and self._streams is not None and self._streams["key"] == self._policy_key(pi_slots)
+        if rows:  # the sampler reset laid the orders out as candidate streams for this policy: row-packed scan
+            keys, _ = self._policy_keys(pi_slots)
+            sm = self._streams
+            smc = L.Streams(dig=L.ptr(sm["dig"]), dig_stride=sm["dig_stride"], loc=L.ptr(sm["loc"]), loc_stride=sm["loc_stride"])
+            L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
+                                                    gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
+            o["_keepalive"] = (pi_d, gp, keys, sm)
+        elif fast and self.state.perm is None and self._perm_lazy == "streams":
+            raise L.OffsimError("the queue orders were laid out for another policy (reset_sampler(policy=...)): call reset_sampler again")
+        elif fast:
             keys = self.compile_policy(pi_d)
             L.check(L.load().offsim_eval_mc_keys(C.byref(t.c), C.byref(self.state.c), L.ptr(keys), float(gamma), L.ptr(gp),
                                                  gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys)
         else:
+            if self.state.perm is None and self._perm_lazy == "streams":
+                self.state.set_orders(self.perm, t.N, self.state.init_perm, self.state.init_stride)  # (materialise the permutations)
             L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
                                             L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp)
@@ -220,6 +325,8 @@ class BatchedPSRS:
 
     def scan_variant(self):
         """Name of the kernel eval_mc's fast path launches for this table and batch size (measurement label)."""
+        if self._streams is not None:
+            return "k_eval_mc_rows"
         return L.load().offsim_eval_mc_keys_kernel(self.table.n_slots, self.R).decode() or "k_eval_mc"
 
     def compile_policy(self, pi_d):
@@ -227,6 +334,7 @@ class BatchedPSRS:
         t = self.table
         if getattr(self, "_keys", None) is None:
             self._keys = torch.empty(max(t.N, 1), dtype=torch.int64, device=t.device)
+        self._pk_cache = None  # (the key buffer is shared with _policy_keys)
         L.check(L.load().offsim_compile_policy(C.byref(t.c), L.ptr(pi_d), L.ptr(self._keys), L.stream_ptr()))
         return self._keys
 
@@ -248,7 +356,7 @@ def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffl
         sd = seeds[b:b + tile]
         if env is None or env.R != len(sd):
             env = BatchedPSRS(table, len(sd), reject_mode)
-        env.reset_sampler(sd, shuffle, shuffle_seed)
+        env.reset_sampler(sd, shuffle, shuffle_seed, policy=pi_slots)
         o = env.eval_mc(pi_slots, gamma, n_episodes)
         for k in outs:
             outs[k].append(o[k].cpu().numpy())

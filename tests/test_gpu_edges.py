@@ -156,16 +156,17 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
             assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
-def test_both_scan_variants_pass_the_parity_suite(variant, gpu):
-    """offsim_eval_mc_keys has two bit-identical kernels (csrc/scan_win.hpp, one wavefront per rollout: the default; and
-    csrc/scan_split.hpp, chain wave + helper wave: picked for 256..3072 rollouts).  OFFSIM_SCAN_SPLIT=0/1 forces one of them
-    and is read once per process: the golden-fixture parity tests, the config tests and the edge cases of this file all run
-    in a child process with each."""
+@pytest.mark.parametrize("variant", ["win", "split"])
+def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
+    """The fast path of eval_mc has three bit-identical kernels: csrc/scan_rows.hpp (four rollouts per wavefront, candidate
+    streams: the default wherever it applies, so the whole in-process suite runs on it), csrc/scan_win.hpp (one wavefront per
+    rollout) and csrc/scan_split.hpp (chain + helper wavefront).  OFFSIM_SCAN_ROWS=0 takes the first out of the choice and
+    OFFSIM_SCAN_SPLIT=0/1 forces one of the others; both are read per process: the golden-fixture parity tests, the config
+    tests and the edge cases of this file run again in a child process for each."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, OFFSIM_SCAN_SPLIT=variant)
+    env = dict(os.environ, OFFSIM_SCAN_ROWS="0", OFFSIM_SCAN_SPLIT="1" if variant == "split" else "0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_configs.py"),
-                        os.path.join(here, "test_gpu_edges.py"), "-m", "gpu", "-x", "-q", "-k", "not both_scan_variants"],
+                        os.path.join(here, "test_gpu_edges.py"), "-m", "gpu", "-x", "-q", "-k", "not every_scan_variant"],
                        env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

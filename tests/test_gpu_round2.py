@@ -324,3 +324,83 @@ def test_sparse_state_ids_and_action_range(gpu):
     a_neg[e["actions"] == 2] = -1  # NumPy: p[-1] is the last column
     wrapped = TransitionTable(e["z"], a_neg, e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
     assert torch.equal(wrapped.a, dense.a)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a2 in its keyed form: the sampler reset writes candidate streams instead of permutations
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,nS,skew", [(64, 1, False), (1001, 7, False), (50_000, 7, True), (120_000, 2, False), (200_000, 162, False)])
+def test_keyed_reset_sampler_streams_equal_the_permutations(N, nS, skew, gpu):
+    """offsim_shuffle_queues_keys (reset_sampler(policy=...)) must describe exactly the queue orders of offsim_shuffle_queues:
+    loc[r][p] = perm[r][p] - seg_off[state of p], dig[r][p] = digest of the compiled key of row perm[r][p]; init orders equal.
+    Covers odd segment lengths and every LDS size class of the shuffle."""
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(N, nS, 2, seed=N + nS)
+    if skew:
+        rng = np.random.default_rng(5)
+        e["z"] = np.where(rng.random(N) < 0.6, 0, rng.integers(0, nS, N)).astype(e["z"].dtype)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    assert table.max_seg <= 65536
+    pi = table.policy_slots(synth.dirichlet_policy(nS, 2))
+    seeds = [0, 7, 2 ** 40 + 3]
+    plain = BatchedPSRS(table, len(seeds))
+    plain.reset_sampler(seeds)
+    keyed = BatchedPSRS(table, len(seeds))
+    keyed.reset_sampler(seeds, policy=pi)
+    assert keyed._streams is not None and keyed.state.perm is None and keyed.scan_variant() == "k_eval_mc_rows"
+    perm = plain.state.perm.to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(keyed.perm.to(torch.int64) & 0xFFFFFFFF, perm)
+    assert torch.equal(keyed.state.init_perm, plain.state.init_perm)
+    keys, dig32 = keyed._policy_keys(pi)
+    assert torch.equal(dig32.to(torch.int64) & 0xFFFFFFFF, (keys >> 32) & 0xFFFFFFFF)
+    assert torch.equal(keyed._streams["dig"], dig32[perm])
+    # and the two forms evaluate identically (row-packed scan on streams vs the window kernels on permutations)
+    cap = N + 1
+    o1 = keyed.eval_mc(pi, 0.97, ep_cap=table.N0 + 1, trace_cap=cap)
+    os.environ["OFFSIM_SCAN_ROWS"] = "0"
+    try:
+        o0 = plain.eval_mc(pi, 0.97, ep_cap=table.N0 + 1, trace_cap=cap)
+    finally:
+        del os.environ["OFFSIM_SCAN_ROWS"]
+    assert plain._streams is None
+    torch.cuda.synchronize()
+    for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status", "trace_row", "trace_pop", "ep_g", "ep_len"):
+        assert torch.equal(o0[k], o1[k]), k
+    assert torch.equal(keyed.state.cursor, plain.state.cursor) and torch.equal(keyed.state.rng, plain.state.rng)
+    assert torch.equal(keyed.state.init_cursor, plain.state.init_cursor) and torch.equal(keyed.state.cur_slot, plain.state.cur_slot)
+
+
+def test_row_packed_scan_matches_the_window_kernel_at_scale(gpu):
+    """2 M transitions x 256 rollouts without trace outputs (the template instance bench.py runs), every per-rollout result
+    of the row-packed scan against the one-wavefront-per-rollout window kernel, plus odd rollout counts (rows of the last
+    wavefront unused) and the shared / table-order modes."""
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS, SHUFFLE_SHARED, SHUFFLE_NONE, SHUFFLE_PER_ROLLOUT
+    N, nS, nA = 2_000_000, 162, 2
+    e = synth.synth_iid(N, nS, nA, seed=11)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    pi = table.policy_slots(synth.dirichlet_policy(nS, nA))
+    for R, mode in ((256, SHUFFLE_PER_ROLLOUT), (13, SHUFFLE_PER_ROLLOUT), (37, SHUFFLE_SHARED), (5, SHUFFLE_NONE)):
+        seeds = list(range(100, 100 + R))
+        a = BatchedPSRS(table, R)
+        a.reset_sampler(seeds, mode, shuffle_seed=99, policy=pi)
+        oa = a.eval_mc(pi, 0.99, dbg=True)
+        assert a.scan_variant() == "k_eval_mc_rows"
+        b = BatchedPSRS(table, R)
+        b.reset_sampler(seeds, mode, shuffle_seed=99)
+        os.environ["OFFSIM_SCAN_ROWS"] = "0"
+        try:
+            ob = b.eval_mc(pi, 0.99)
+        finally:
+            del os.environ["OFFSIM_SCAN_ROWS"]
+        torch.cuda.synchronize()
+        for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status"):
+            assert torch.equal(oa[k], ob[k]), (R, mode, k)
+        assert torch.equal(a.state.cursor, b.state.cursor) and torch.equal(a.state.rng, b.state.rng)
+        dbg = oa["dbg"].cpu().numpy()
+        assert (dbg[:, 0] + dbg[:, 1]).sum() < 0.05 * oa["steps"].sum().item()  # exact-path events stay rare
