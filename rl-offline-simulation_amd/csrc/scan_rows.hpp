@@ -11,13 +11,15 @@
 //   * windows are HEAD-ALIGNED: entry j of a state's 8-entry row is the j-th candidate still queued (0 = none loaded).
 //     Accepting entry k pushes entries k+1.. to the front with one ds_write (lane j stores to slot (j-k-1) mod 8, the
 //     vacated slots get 0), so the next look at that state needs no cursor to find its candidates;
-//   * lanes 0..7 of a row compare draw c+j (ring of pre-shifted 21-bit draws) with digest j in one v_sub_co; the winner
-//     (first lane that is not a clear reject) and its payload (done, z_next, a "needs an exact look" field) are found by
-//     a 4-step DPP min over key = (j+1) << 28 | clear << 11 | done << 10 | z_next (clear: digest - draw >= 2^15);
-//   * anything that is not a clean accept -- tie on 21 bits, no candidate accepted, window dry, episode end, draws
-//     running low -- is an event: every row that has one goes through handle() (exact, reads the stream directly) while
-//     the rows without one commit their step; all rows therefore take exactly one accepted step per iteration and the
-//     iteration / log index is wave-uniform (scalar).
+//   * entries are stored BIASED, digest - 16 units of T21 (0 if that is negative), and the ring holds the draws as
+//     k21 << 11 | 1: then "draw <= entry" (one v_sub_co, its borrow) is a CLEAR accept -- the candidate's threshold is
+//     above the draw by 16 units or more -- and "entry < draw <= entry + 17 units" (one v_cmp on the difference) marks the
+//     lanes that need the exact 53-bit look.  Lanes 0..7 of a row test draw c+j against entry j; the first clear accept
+//     and its payload (done, z_next) come out of a 4-step DPP min over key = (j+1) << 28 | done << 10 | z_next;
+//   * anything else -- a lane near a tie anywhere in the wavefront, no clear accept in a row, window dry, episode end,
+//     draws running low -- is an event: the hand-scheduled loop is left, every row that has an event goes through
+//     handle() (exact, reads the stream directly) while the rows without one commit their step; all rows therefore take
+//     exactly one accepted step per iteration and the iteration / log index is wave-uniform (scalar).
 // Candidates come from the per-rollout digest stream written by the sampler reset (offsim_shuffle_queues_keys): the
 // refill reads 16 consecutive bytes of it per request instead of gathering 4-byte digests through a permutation
 // (64-byte sector each).  Every 16 iterations one tick runs, per row with lane = step: land last tick's requests,
@@ -37,10 +39,11 @@ namespace offsim {
 #define ROWS_TICK 16u
 #define ROWS_RING 128u
 #define ROWS_W 8u
-#define ROWS_EMPTY 0x400u  // window slot without a candidate: T21 = 0 and the done bit, so that it can win only as an event
+#define ROWS_EMPTY 0u      // window slot without a candidate (a draw is never <= 0: ring entries carry a set low bit)
+#define ROWS_BIAS 0x8000u  // window entries are digest - 16 units of T21: "draw <= entry" is then a CLEAR accept
+#define ROWS_AMB 0xffff7800u  // entry - draw >= this (i.e. the draw exceeds the entry by at most 17 units): the exact look decides
 // per-rollout LDS region (byte offsets); window rows are 32-byte aligned, the region a multiple of 512
 #define RO_RING 0u       // 128 draws, (k21 << 11)
-#define RO_JUNKROW 512u  // 32 B: the "window row" of lanes 8..15 (read and written, never meaningful)
 #define RO_PAD 544u      // 0xffffffff: the "draw" of lanes 8..15, so that they never win
 #define RO_INIT 576u     // 16 upcoming initial states (slot or -1)
 #define RO_LOG 640u      // 16 x {cursor behind the accepted candidate, state left | done << 10}; reused as the prod scratch
@@ -54,6 +57,28 @@ typedef __attribute__((address_space(3))) volatile double ldsv_f64;
 #define LV64(a) (*(ldsv_u32x2 *)(a))
 
 __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 44u + 511u) & ~511u; }
+
+// Per-wavefront landing area of the tick's global loads.  They are issued as LDS-DMA (global_load_lds_dword: no VGPR
+// destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
+// it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
+// orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
+enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_SLOTS };
+#define ROWS_DMA_BYTES 2560u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 512 (the rollout regions behind it stay 512-byte aligned)
+
+__device__ __forceinline__ uint32_t rows_bias(uint32_t dig) { return dig >= ROWS_BIAS ? dig - ROWS_BIAS : 0u; }
+
+__device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_dst_uniform)
+        : "memory");
+}
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t row_dpp(uint32_t x) {
@@ -95,22 +120,22 @@ __global__ void __launch_bounds__(256)
     const uint32_t rpb = blockDim.x >> 4;  // rollouts per block
     const uint32_t rid = wave * 4u + rw;
     const int64_t r = (int64_t)blockIdx.x * rpb + rid;
-    const uint32_t rbase = seg_a + seg_bytes + rid * region_bytes;
+    const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this wavefront's DMA slots
+    const uint32_t rbase = seg_a + seg_bytes + (blockDim.x >> 6) * ROWS_DMA_BYTES + rid * region_bytes;
+    auto dma_slot = [&](uint32_t slot) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
     const uint32_t win_a = rbase + RO_WIN, cons_a = win_a + n_slots * 32u, land_a = cons_a + n_slots * 4u, claim_a = land_a + n_slots * 4u;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
 
-    // per-lane constants that neutralise lanes 8..15 of every row inside the chain loop without a predicate: their window
-    // row is the junk row (state multiplier 0), their draw is the pad word, their shifted stores land in the junk row
+    // Lanes 8..15 of a row look at the same window entries as lanes 0..7 but against the pad "draw" 0xffffffff, so they
+    // never hold the row's minimum; window stores are done by lanes 0..7 only.
     const bool lower = li < 8u;
-    const uint32_t scale_l = lower ? 32u : 0u;
-    const uint32_t win_rd_l = lower ? win_a + li4 : rbase + RO_JUNKROW + (li4 - 32u);
-    const uint32_t win_w_l = lower ? win_a : rbase + RO_JUNKROW;
+    const uint32_t li4w = (li & 7u) * 4u;
+    const uint32_t win_rd_l = win_a + li4w;
     const uint32_t rmask_l = lower ? (ROWS_RING * 4u - 4u) : 0u;
     const uint32_t rbase_l = lower ? rbase + RO_RING : rbase + RO_PAD;
     const uint32_t lifield = (li + 1u) << 28;
 
-    if (li < 8u) LV32(rbase + RO_JUNKROW + li4) = ROWS_EMPTY;
     if (li == 8u) LV32(rbase + RO_PAD) = 0xffffffffu;
     __syncthreads();
     auto seg_at = [&](uint32_t s) -> uint32_t { return LV32(seg_a + s * 4u); };
@@ -130,13 +155,13 @@ __global__ void __launch_bounds__(256)
         const uint32_t c0 = cur_glb[s], beg = seg_at(s), len = seg_at(s + 1u) - beg;
         const uint32_t left = len - c0, want = left < ROWS_W ? left : ROWS_W;
 #pragma unroll
-        for (uint32_t e = 0; e < ROWS_W; e++) LV32(win_a + s * 32u + e * 4u) = e < want ? dbase[beg + c0 + e] : ROWS_EMPTY;
+        for (uint32_t e = 0; e < ROWS_W; e++) LV32(win_a + s * 32u + e * 4u) = e < want ? rows_bias(dbase[beg + c0 + e]) : ROWS_EMPTY;
         LV32(cons_a + s * 4u) = c0;
         LV32(land_a + s * 4u) = c0 + want;
         LV32(claim_a + s * 4u) = 0u;
     }
 
-    // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of the top 21 bits, pre-shifted ----
+    // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of k21 << 11 | 1 ----
     U128 lane_state;
     U128 plus16;
     {
@@ -147,7 +172,7 @@ __global__ void __launch_bounds__(256)
     const U128 mult16 = u128(0xb6a4239f3b315f84ull, 0xf6ef6d3d288c03c1ull);  // PCG multiplier ** 16 mod 2**128
     uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start (every examined candidate = one draw)
     auto gen16 = [&]() {
-        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = (uint32_t)(pcg_output(lane_state) >> 43) << 11;
+        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = ((uint32_t)(pcg_output(lane_state) >> 43) << 11) | 1u;
         lane_state = add128(mul128(mult16, lane_state), plus16);
         gen += 16u;
     };
@@ -172,11 +197,11 @@ __global__ void __launch_bounds__(256)
     uint32_t pop_acc = 0;    // candidates popped so far by the step in progress (TRACE)
     uint32_t n_dry = 0, n_tie = 0, n_tick = 0;
     // refill: one outstanding request per lane
-    uint32_t rq_s = 0, rq_p = 0, rq_n = 0, rq_d0 = 0, rq_d1 = 0, rq_d2 = 0, rq_d3 = 0;
+    uint32_t rq_s = 0, rq_p = 0, rq_n = 0;
     // reward pipeline, three ticks deep (R1: row index + discount, R2: reward, R3: in-order sums)
-    uint32_t loc1 = 0, rowb1 = 0, pop1 = 0, n1 = 0, n2 = 0, dm1 = 0, dm2 = 0, st1 = 0;
+    uint32_t rowb1 = 0, half1 = 0, pop1 = 0, n1 = 0, n2 = 0, dm1 = 0, dm2 = 0, st1 = 0;
     uint64_t any1 = 0, any2 = 0;
-    double gp1 = 0.0, gp2 = 0.0, rv2 = 0.0;
+    double gp2 = 0.0;
     uint32_t tt_chain = 0, steps = 0, ep_acc = 0, n_len = 0, len_acc = 0;
     double G = 0.0, sum_g = 0.0;
 
@@ -200,20 +225,26 @@ __global__ void __launch_bounds__(256)
     };
     if (!dead) do_reset(0u);
 
-    // chain-loop registers
-    uint32_t vrow_rd = 0, vrow_w = 0, vcons = 0, dig = 0, kt = 0, cz = 0;
+    // chain registers: w = this lane's window entry of the current state, kt = its draw, cz = the state's cursor
+    uint32_t vrow_w = 0, vcons = 0, w = 0, kt = 0, cz = 0;
     auto issue_reads = [&]() {
         const uint32_t zz = dead ? 0u : z;
-        vrow_rd = zz * scale_l + win_rd_l;
-        vrow_w = zz * scale_l + win_w_l;
+        vrow_w = win_a + zz * 32u;
         vcons = cons_a + zz * 4u;
         const uint32_t ra = (((c << 2) + li4) & rmask_l) | rbase_l;
-        dig = LV32(vrow_rd);
         kt = LV32(ra);
+        w = LV32(vrow_w + li4w);
         cz = LV32(vcons);
     };
+    // the look of the hand-scheduled loop, restated for the iterations that run outside it (some row of the wavefront has
+    // stopped, or TRACE): key as there, amb = some lane of the row needs the exact look
+    auto look = [&](uint32_t &key, bool &amb) {
+        const uint32_t d = w - kt;
+        key = row_min16(kt > w ? 0xffffffffu : ((w & 0x7ffu) | lifield));
+        amb = row_min16(lower && d >= ROWS_AMB ? 0u : 1u) == 0u;
+    };
 
-    // the step's bookkeeping for a clean accept of window entry k1-1 with digest payload `key`
+    // the step's bookkeeping for a clear accept of window entry k1-1 with payload `key`
     auto commit = [&](uint32_t key, uint32_t k1, uint32_t it) {
         c += k1;
         const uint32_t cz1 = cz + k1;
@@ -227,8 +258,7 @@ __global__ void __launch_bounds__(256)
             pop_acc = 0;
         }
         const uint32_t k1x4 = k1 << 2;
-        const uint32_t data = li4 < k1x4 ? ROWS_EMPTY : dig;
-        LV32(((li4 - k1x4) & (lower ? 28u : 0u)) | vrow_w) = data;
+        if (lower) LV32(((li4 - k1x4) & 28u) | vrow_w) = li4 < k1x4 ? ROWS_EMPTY : w;
         z = key & 0x3ffu;
     };
 
@@ -255,9 +285,9 @@ __global__ void __launch_bounds__(256)
             const uint32_t nv = rem < 16u ? rem : 16u;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
-            const uint32_t kk = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2));
-            bool ok = valid && kk <= dg;
-            if (ok && dg - kk < 2048u) {  // top-21-bit tie: k53 of draw c+li against the full T
+            const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> 11;
+            bool ok = valid && k21 <= (dg >> 11);
+            if (ok && k21 == (dg >> 11)) {  // top-21-bit tie: k53 of draw c+li against the full T
                 const uint32_t lc = lbase ? (uint32_t)lbase[beg + cz + li] : cz + li;
                 ok = !(rows_exact53(rng4, (uint64_t)c + li + 1u) > key_T(keys[beg + lc]));
             }
@@ -283,7 +313,7 @@ __global__ void __launch_bounds__(256)
             }
             const uint32_t keep = nv - k1 < ROWS_W ? nv - k1 : ROWS_W;  // the candidates behind it become the window
             if (li < 8u) LV32(win_a + z * 32u + li4) = ROWS_EMPTY;
-            if (li >= k1 && li < k1 + keep) LV32(win_a + z * 32u + ((li - k1) << 2)) = dg;
+            if (li >= k1 && li < k1 + keep) LV32(win_a + z * 32u + ((li - k1) << 2)) = rows_bias(dg);
             LV32(land_a + z * 4u) = cz1 + keep;
             z = acc & 0x3ffu;
             if (acc & 0x400u) {
@@ -294,23 +324,21 @@ __global__ void __launch_bounds__(256)
         }
     };
 
-    // a row whose look was not a clean accept (key from the chain loop's reduction, valid in all 16 lanes)
-    auto handle = [&](uint32_t key, uint32_t it) {
-        const uint32_t k1 = key >> 28;
-        const uint32_t v = LV32(land_a + z * 4u) - cz;  // candidates the window really holds (the others are ROWS_EMPTY)
-        if (key != 0xffffffffu && (key & 0x800u) && k1 - 1u < v) {  // clean accept: the event is the episode end or low draws
-            commit(key, k1, it);
+    // one iteration of a live row outside the hand-scheduled loop
+    auto slow_step = [&](uint32_t key, bool amb, uint32_t it) {
+        if (key != 0xffffffffu && !amb) {  // clear accept: the row's event, if any, is the episode end or low draws
+            commit(key, key >> 28, it);
             if (key & 0x400u) {
                 ep++;
                 do_reset(it + 1u);
             }
         } else {
-            uint32_t nrej;  // clear rejects in front of the first candidate that needs the exact look
-            if (key == 0xffffffffu || k1 - 1u >= v) {  // every candidate of the window rejected (an empty slot cannot be accepted)
+            uint32_t nrej = 0;  // with a lane near a tie the exact look starts at the head of the queue
+            if (!amb) {         // every candidate the window holds is a clear reject
+                const uint32_t v = LV32(land_a + z * 4u) - cz;
                 nrej = v < ROWS_W ? v : ROWS_W;
                 n_dry++;
             } else {
-                nrej = k1 - 1u;
                 n_tie++;
             }
             c += nrej;
@@ -321,8 +349,23 @@ __global__ void __launch_bounds__(256)
         while (!dead && gen - c < 48u) gen16();
     };
 
+#ifdef OFFSIM_ROWS_PROF
+    uint64_t pf_fast = 0, pf_slow = 0, pf_tick = 0, pf_nslow = 0, pf_t0 = 0, pf_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t1 = 0;
+#define PF_START() pf_t0 = __builtin_amdgcn_s_memtime()
+#define PF_ADD(x) x += __builtin_amdgcn_s_memtime() - pf_t0
+#define PF_PH(k) { const uint64_t _n = __builtin_amdgcn_s_memtime(); pf_ph[k] += _n - pf_t1; pf_t1 = _n; }
+#else
+#define PF_PH(k)
+#define PF_START()
+#define PF_ADD(x)
+#endif
     // ---- once per 16 iterations; lane = step of the tick ----
     auto tick = [&]() {
+#ifdef OFFSIM_ROWS_PROF
+        pf_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
+        PF_PH(0);
         const uint32_t n = dead ? nlog_dead : ROWS_TICK;
         nlog_dead = 0;
         n_tick++;
@@ -332,23 +375,29 @@ __global__ void __launch_bounds__(256)
         const bool done_i = mine && (le.y & 0x400u);
         uint32_t pop_i = 0;
         if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
+        // everything the previous tick's loads brought, before the slots are reused
+        const uint32_t in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+        const uint32_t in_loc = dma_slot(DS_LOC), in_gplo = dma_slot(DS_GPLO), in_gphi = dma_slot(DS_GPHI);
+        const uint32_t in_rlo = dma_slot(DS_RLO), in_rhi = dma_slot(DS_RHI);
 
+        PF_PH(1);
         // C: land the digests requested one tick ago.  Entries are appended only at the window's current end: whatever a
         // direct read has covered meanwhile is skipped, whatever does not fit is requested again later.
         if (rq_n) {
             const uint32_t cs = LV32(cons_a + rq_s * 4u);
             uint32_t ld = LV32(land_a + rq_s * 4u);
-            const uint32_t dd[4] = {rq_d0, rq_d1, rq_d2, rq_d3};
+            const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
 #pragma unroll
             for (uint32_t e = 0; e < 4u; e++) {
                 if (e < rq_n && rq_p + e == ld && ld - cs < ROWS_W) {
-                    LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = dd[e];
+                    LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = rows_bias(dd[e]);
                     ld++;
                 }
             }
             LV32(land_a + rq_s * 4u) = ld;
             rq_n = 0;
         }
+        PF_PH(2);
         // A: one request per state left in this tick (the lane that logged the step tops the state up)
         if (mine) LV32(claim_a + s_i * 4u) = li;
         if (mine && LV32(claim_a + s_i * 4u) == li) {
@@ -359,20 +408,23 @@ __global__ void __launch_bounds__(256)
             want = want < 4u ? want : 4u;
             if (want) {
                 const uint32_t *src = dbase + beg + ld;
-                rq_d0 = src[0];
-                if (want > 1u) rq_d1 = src[1];
-                if (want > 2u) rq_d2 = src[2];
-                if (want > 3u) rq_d3 = src[3];
+                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
+                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
+                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
+                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
                 rq_s = s_i;
                 rq_p = ld;
                 rq_n = want;
             }
         }
 
+        PF_PH(3);
         // R3: in-order discounted-return accumulation (psrs.py:262-269) for the steps of two ticks ago: the products are
         // broadcast through LDS, every lane of the row runs the same sequential sum (bit-exact Gs)
         {
-            const double prod = li < n2 ? gp2 * rv2 : 0.0;  // product first, then the running sum in step order (+0.0 changes nothing)
+            double rv = 0.0;
+            if (li < n2) rv = r64 ? __hiloint2double((int)in_rhi, (int)in_rlo) : (double)__uint_as_float(in_rlo);
+            const double prod = li < n2 ? gp2 * rv : 0.0;  // product first, then the running sum in step order (+0.0 changes nothing)
             *(ldsv_f64 *)(rbase + RO_LOG + li * 8u) = prod;
             double p[16];
 #pragma unroll
@@ -402,40 +454,59 @@ __global__ void __launch_bounds__(256)
             }
             len_acc = (uint32_t)(base_len + (int32_t)n2);
         }
-        // R2: rewards of the steps of one tick ago
+        PF_PH(4);
+        // R2: rewards of the steps of one tick ago (row = segment start + local row, the latter from the loc stream)
         {
-            double rv = 0.0;
             if (li < n1) {
-                const uint32_t g = rowb1 + loc1;
-                rv = r64 ? ((const double *)t.r)[g] : (double)((const float *)t.r)[g];
+                const uint32_t lc = lbase ? ((half1 ? in_loc >> 16 : in_loc) & 0xffffu) : in_loc;
+                const uint32_t g = rowb1 + lc;
+                if (r64) {
+                    const uint32_t *src = (const uint32_t *)((const double *)t.r + g);
+                    lds_dma_dword(src, dma_a + DS_RLO * 256u);
+                    lds_dma_dword(src + 1, dma_a + DS_RHI * 256u);
+                } else {
+                    lds_dma_dword((const float *)t.r + g, dma_a + DS_RLO * 256u);
+                }
                 if (TRACE) {
                     const uint32_t st = st1 + li;
                     if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[r * out.trace_cap + st] = t.orig_idx[g];
                     if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[r * out.trace_cap + st] = pop1;
                 }
             }
-            rv2 = rv;
-            gp2 = gp1;
+            gp2 = __hiloint2double((int)in_gphi, (int)in_gplo);
             dm2 = dm1;
             any2 = any1;
             n2 = n1;
         }
-        // R1: row index (through the stream of local indices) and discount factor of this tick's steps
+        PF_PH(5);
+        // R1: local row (the aligned dword of the 16-bit loc stream that holds it) and discount factor of this tick's steps
         {
             const uint64_t bal = __ballot(done_i);
             const uint32_t dmrow = (uint32_t)(bal >> (rw * 16u)) & 0xffffu;  // episode ends of this row's tick
-            uint32_t lc = 0, rb = 0;
-            double gp = 0.0;
+            uint32_t rb = 0, hf = 0;
             if (mine) {
                 rb = seg_at(s_i);
-                lc = lbase ? (uint32_t)lbase[rb + pos_i] : pos_i;
+                if (lbase) {
+                    const uint64_t a16 = (uint64_t)(uintptr_t)(lbase + rb + pos_i);
+                    hf = (uint32_t)(a16 >> 1) & 1u;
+                    lds_dma_dword((const void *)(uintptr_t)(a16 & ~3ull), dma_a + DS_LOC * 256u);
+                } else {
+                    LV32(dma_a + DS_LOC * 256u + lane * 4u) = pos_i;  // table order: the local row is the queue position
+                }
                 const uint32_t below = dmrow & ((1u << li) - 1u);  // episode ends earlier in this tick
                 const uint32_t t_i = below ? li - 1u - (31u - (uint32_t)__clz((int)below)) : tt_chain + li;
-                gp = discount_at(gamma_pow, n_gamma_pow, gamma, (uint64_t)t_i);
+                if ((uint64_t)t_i < n_gamma_pow) {
+                    const uint32_t *src = (const uint32_t *)(gamma_pow + t_i);
+                    lds_dma_dword(src, dma_a + DS_GPLO * 256u);
+                    lds_dma_dword(src + 1, dma_a + DS_GPHI * 256u);
+                } else {  // beyond the host's table (csrc/discount.hpp)
+                    const double gp = discount_beyond_table(gamma_pow, n_gamma_pow, gamma, (uint64_t)t_i);
+                    LV32(dma_a + DS_GPLO * 256u + lane * 4u) = (uint32_t)__double2loint(gp);
+                    LV32(dma_a + DS_GPHI * 256u + lane * 4u) = (uint32_t)__double2hiint(gp);
+                }
             }
-            loc1 = lc;
             rowb1 = rb;
-            gp1 = gp;
+            half1 = hf;
             pop1 = pop_i;
             dm1 = dmrow;
             any1 = (bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull;
@@ -444,68 +515,126 @@ __global__ void __launch_bounds__(256)
             tt_chain = dmrow ? n - 1u - (31u - (uint32_t)__clz((int)dmrow)) : tt_chain + n;
             steps += n;
         }
+        PF_PH(6);
         if (!dead) {
             if (ic - ib >= 8u) load_init();
             while (gen - c < 112u) gen16();
         }
+        PF_PH(7);
     };
 
     // ---- the chain ----
-    // One iteration = one accepted step of every live row.  The inner loop holds nothing but the clean-accept path and is
-    // left through one wave-uniform branch as soon as ANY row has an event; that iteration is then redone row by row
-    // (rows without an event commit, the others go through handle()), and the fast loop is entered again.
-    const uint32_t c7ff = 0x7ffu;
-    for (;;) {
+    // One iteration = one accepted step of every live row.  fast_run() is the hand-scheduled loop: nothing but the
+    // clear-accept path, left through one wave-uniform branch as soon as ANY lane of the wavefront sees something else; that
+    // iteration is then redone row by row (rows without an event commit, the others take the exact path), and the loop is
+    // entered again.  TRACE builds and wavefronts with a stopped row run every iteration the second way.
+    //
+    // Instruction order inside the loop: the draw of the NEXT look is requested as soon as the number of consumed candidates
+    // is known (its ring address needs nothing else); the window entry and the cursor of the next state are requested
+    // behind this step's three LDS stores (cursor, shifted row, log), because the next state may be this one.
+    uint32_t amb_lo = 0, amb_hi = 0;
+    auto fast_run = [&](uint32_t &it, uint32_t &key) {
+        uint32_t c4 = (c << 2) + li4;                      // draw counter, as the byte offset of this lane's ring slot
+        const uint32_t lim4 = ((gen - 24u) << 2) + li4;    // c4 beyond this leaves fewer than 24 draws
+        uint32_t zz = z, logaddr = rbase + RO_LOG + it * 8u - 8u;
+        uint32_t k4, k1, d, tt, nrd;
+        uint64_t amb;
+        const uint64_t lowexec = 0x00ff00ff00ff00ffull;
+        asm volatile(
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"                                   // the draw and the window entry (the cursor may still be out)
+            "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    // borrow: not a clear accept
+            "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             // (lane + 1) << 28 | done << 10 | z_next
+            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 // the draw is above the entry by <= 17 units of T21: exact look
+            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"
+            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"
+            "s_and_b64 %[amb], %[amb], %[lowexec]\n\t"                  // (lanes 8..15 test the pad draw: meaningless)
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %[key], %[key], %[key] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        // 4 x candidates consumed by this step
+            "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             // this lane's entry in the next state's row
+            "v_add_u32 %[c4], %[c4], %[k4]\n\t"
+            "v_and_or_b32 %[tt], %[c4], %[rmask], %[rbase]\n\t"
+            "ds_read_b32 %[kt], %[tt]\n\t"                               // next look's draw
+            "v_sub_u32 %[tt], %[lim4], %[c4]\n\t"                        // negative: draws run low
+            "v_and_b32 %[tt], %[ssign], %[tt]\n\t"
+            "v_and_or_b32 %[tt], %[key], %[s400], %[tt]\n\t"             // | episode end (also set in the all-ones key of a row without a clear accept)
+            "v_cmp_ne_u32_e32 vcc, 0, %[tt]\n\t"
+            "s_or_b64 vcc, vcc, %[amb]\n\t"
+            "s_cbranch_vccnz 2f\n\t"
+            // ---- no lane of the wavefront has an event: commit the step of all four rows ----
+            "v_lshrrev_b32 %[k1], 28, %[key]\n\t"
+            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               // slot (x4) of this lane's entry after the shift; borrow: it was consumed
+            "s_waitcnt lgkmcnt(1)\n\t"                                   // the cursor (only the draw requested above may be out)
+            "v_add_u32 %[cz], %[cz], %[k1]\n\t"
+            "v_cndmask_b32_e64 %[d], %[w], 0, vcc\n\t"
+            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"
+            "ds_write_b32 %[vcons], %[cz]\n\t"
+            "s_mov_b64 exec, %[lowexec]\n\t"
+            "ds_write_b32 %[tt], %[d]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "ds_write2_b32 %[logaddr], %[cz], %[zz] offset1:1\n\t"      // {cursor behind the accepted candidate, state left}
+            "ds_read_b32 %[w], %[nrd]\n\t"
+            "v_and_b32 %[zz], 0x3ff, %[key]\n\t"
+            "v_lshl_add_u32 %[vcons], %[zz], 2, %[consa]\n\t"
+            "v_lshl_add_u32 %[vrow], %[zz], 5, %[wina]\n\t"
+            "ds_read_b32 %[cz], %[vcons]\n\t"
+            "s_add_u32 %[it], %[it], 1\n\t"
+            "s_cmp_lt_u32 %[it], 16\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b64 %[amb], 0\n\t"
+            "s_branch 3f\n\t"
+            "2:\n\t"
+            "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
+            "3:\n\t"
+            "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
+            : [w] "+v"(w), [kt] "+v"(kt), [cz] "+v"(cz), [c4] "+v"(c4), [vrow] "+v"(vrow_w), [vcons] "+v"(vcons), [zz] "+v"(zz),
+              [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [k1] "=&v"(k1), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
+              [amb] "=&s"(amb), [it] "+s"(it)
+            : [lif] "v"(lifield), [rmask] "v"(rmask_l), [rbase] "v"(rbase_l), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a),
+              [li4w] "v"(li4w), [lim4] "v"(lim4), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [ssign] "s"(0x80000000u),
+              [lowexec] "s"(lowexec)
+            : "vcc", "memory");
+        c = (c4 - li4) >> 2;
+        z = zz;
+        amb_lo = (uint32_t)amb;
+        amb_hi = (uint32_t)(amb >> 32);
+    };
+
+    for (uint32_t drained = 0;;) {
         uint32_t it = 0;
-        issue_reads();
+        if (drained) it = ROWS_TICK;  // every row has stopped: only the reward pipeline is still draining
         while (it < ROWS_TICK) {
-            uint32_t key = 0, k1 = 0;
-            bool ev = false;
-            for (;;) {
-                uint32_t tmp;
-                // key = (first lane of the row that is not a clear reject + 1) << 28 | clear << 11 | done << 10 | z_next, where
-                // clear = the digest exceeds the draw by at least 16 units of T21 (anything closer gets the exact look);
-                // all ones if every lane is a clear reject.  The 4-step row minimum leaves it in all 16 lanes.
-                asm volatile(
-                    "v_sub_co_u32 %0, vcc, %2, %3\n\t"
-                    "v_and_or_b32 %1, %2, %4, %5\n\t"
-                    "v_lshrrev_b32 %0, 15, %0\n\t"
-                    "v_min_u32 %0, 1, %0\n\t"
-                    "v_lshl_or_b32 %0, %0, 11, %1\n\t"
-                    "v_cndmask_b32_e64 %0, %0, -1, vcc\n\t"
-                    "s_nop 1\n\t"
-                    "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "s_nop 1\n\t"
-                    "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "s_nop 1\n\t"
-                    "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                    "s_nop 1\n\t"
-                    "v_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
-                    : "=&v"(key), "=&v"(tmp)
-                    : "v"(dig), "v"(kt), "s"(c7ff), "v"(lifield)
-                    : "vcc");
-                k1 = key >> 28;
-                const uint32_t low = (gen - 24u) - (c + k1);  // negative: fewer than 24 draws would be left
-                ev = (((low & 0x80000000u) | (key & 0xc00u) | dead) != 0x800u);  // not {clear, episode goes on, draws left, row live}
-                if (__builtin_expect(__ballot(ev) != 0ull, 0)) break;
-                commit(key, k1, it);
-                it++;
+            issue_reads();
+            uint32_t key = 0;
+            bool amb = false;
+            if (!TRACE && __ballot(dead != 0u) == 0ull) {
+                PF_START();
+                fast_run(it, key);
+                PF_ADD(pf_fast);
                 if (it == ROWS_TICK) break;
-                issue_reads();
+                amb = (((rw & 2u) ? amb_hi : amb_lo) >> ((rw & 1u) * 16u) & 0xffffu) != 0u;
+            } else {
+                look(key, amb);
             }
-            if (it == ROWS_TICK) break;
-            if (!dead) {
-                if (!ev) commit(key, k1, it);
-                else handle(key, it);
-            }
+            PF_START();
+            if (!dead) slow_step(key, amb, it);
             it++;
-            if (it < ROWS_TICK) issue_reads();
+            PF_ADD(pf_slow);
+#ifdef OFFSIM_ROWS_PROF
+            pf_nslow++;
+#endif
         }
+        PF_START();
         tick();
-        if (__ballot(!dead) == 0ull) break;
+        PF_ADD(pf_tick);
+        if (__ballot(!dead) == 0ull && ++drained == 3u) break;  // two more ticks drain the reward pipeline (R2, R3)
     }
-    tick();  // drain the reward pipeline (R2, R3 of the last ticks)
-    tick();
     if (status == OFFSIM_ST_EXHAUSTED) {  // psrs.py:265: the cut-short episode still logs its length
         if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
         n_len++;
@@ -528,12 +657,23 @@ __global__ void __launch_bounds__(256)
             out.cand[r] = c;
             out.n_len[r] = n_len;
             out.status[r] = status;
+#ifdef OFFSIM_ROWS_PROF
+            if (out.dbg) {
+                out.dbg[4 * r + 0] = (int64_t)pf_fast;
+                out.dbg[4 * r + 1] = (int64_t)pf_slow;
+                out.dbg[4 * r + 2] = (int64_t)pf_tick;
+                out.dbg[4 * r + 3] = (int64_t)(pf_nslow | ((uint64_t)n_dry << 32));
+                if (out.ep_g && out.ep_cap >= 8)
+                    for (int k = 0; k < 8; k++) out.ep_g[r * out.ep_cap + k] = (double)pf_ph[k];
+            }
+#else
             if (out.dbg) {
                 out.dbg[4 * r + 0] = n_dry;
                 out.dbg[4 * r + 1] = n_tie;
                 out.dbg[4 * r + 2] = n_tick;
                 out.dbg[4 * r + 3] = gen / 16u;
             }
+#endif
         }
     }
 }

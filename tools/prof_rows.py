@@ -1,0 +1,26 @@
+"""In-kernel cycle stamps of the row-packed scan (library built with -DOFFSIM_ROWS_PROF): where an iteration's cycles go."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rl_offline_simulation_amd import synth
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+N, R = int(sys.argv[1]), int(sys.argv[2])
+e = synth.synth_iid(N, 162, 2, seed=20221107)
+table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+pi = table.policy_slots(synth.dirichlet_policy(162, 2))
+env = BatchedPSRS(table, R)
+env.reset_sampler(list(range(R)), policy=pi)
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record(); o = env.eval_mc(pi, 0.99, dbg=True, ep_cap=8); t1.record(); torch.cuda.synchronize()
+d = o["dbg"].cpu().numpy()[::16]  # one lane-0 row per wavefront is enough (all rows of a wave stamp the same clock)
+steps = o["steps"].cpu().numpy().astype(float)
+it = steps.max()
+fast, slow, tick = d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean()
+nslow = (d[:, 3] & 0xffffffff).mean(); ndry = (d[:, 3] >> 32).mean()
+print(f"kernel {t0.elapsed_time(t1):.1f} ms, iterations/wave ~{it:.0f}")
+print(f"memtime ticks per iteration: fast {fast / it:.1f} slow {slow / it:.1f} tick {tick / it:.1f}  (total {(fast + slow + tick) / it:.1f})")
+print(f"slow iterations {nslow / it * 100:.2f} % of all, {slow / max(nslow, 1):.0f} ticks each; tick() {tick / (it / 16):.0f} ticks each; dry events/row {ndry:.0f}")
+ph = o["ep_g"].cpu().numpy()[::16].mean(axis=0)
+names = ["vmcnt wait", "log+slot reads", "C land", "A request", "R3 sums", "R2 rewards", "R1 loc/discount", "init ring + draws"]
+print("tick phases (cycles per tick):", {n: int(v / (it / 16)) for n, v in zip(names, ph)})
