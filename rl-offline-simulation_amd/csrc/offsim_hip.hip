@@ -1045,12 +1045,12 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     const bool trace = out->trace_row || out->trace_pop;
     // four rollouts per wavefront; as many wavefronts per workgroup (<= 4) as the CU's 160 KiB of LDS hold regions for
     const uint32_t region = rows_region_bytes((uint32_t)t->n_slots);
-    const uint32_t seg_bytes = (((uint32_t)t->n_slots + 1u) * 4u + 511u) & ~511u;
-    int waves = (int)((160u * 1024u - 512u - seg_bytes) / (4u * region + ROWS_DMA_BYTES));
+    const uint32_t seg_bytes = (((uint32_t)t->n_slots + 1u) * 4u + 1023u) & ~1023u;
+    int waves = (int)((160u * 1024u - 1024u - seg_bytes) / (4u * region + ROWS_DMA_BYTES));
     waves = waves > 4 ? 4 : waves;
     if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
     const int rpb = waves * 4;
-    const size_t lds = 512 + seg_bytes + (size_t)waves * ROWS_DMA_BYTES + (size_t)rpb * region;
+    const size_t lds = 1024 + seg_bytes + (size_t)waves * ROWS_DMA_BYTES + (size_t)rpb * region;
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb)), block((unsigned)(waves * 64));
     if (trace) {
         HIP_TRY(allow_big_lds(k_eval_mc_rows<true>, 160 * 1024));

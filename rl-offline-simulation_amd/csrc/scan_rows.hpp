@@ -37,18 +37,17 @@
 namespace offsim {
 
 #define ROWS_TICK 16u
-#define ROWS_RING 128u
+#define ROWS_RING 256u
 #define ROWS_W 8u
 #define ROWS_EMPTY 0u      // window slot without a candidate (a draw is never <= 0: ring entries carry a set low bit)
 #define ROWS_BIAS 0x8000u  // window entries are digest - 16 units of T21: "draw <= entry" is then a CLEAR accept
 #define ROWS_AMB 0xffff7800u  // entry - draw >= this (i.e. the draw exceeds the entry by at most 17 units): the exact look decides
 // per-rollout LDS region (byte offsets); window rows are 32-byte aligned, the region a multiple of 512
-#define RO_RING 0u       // 128 draws, (k21 << 11)
-#define RO_PAD 544u      // 0xffffffff: the "draw" of lanes 8..15, so that they never win
-#define RO_INIT 576u     // 16 upcoming initial states (slot or -1)
-#define RO_LOG 640u      // 16 x {cursor behind the accepted candidate, state left | done << 10}; reused as the prod scratch
-#define RO_POP 768u      // 16 x candidates popped by the step (TRACE)
-#define RO_WIN 1024u     // n_slots x 8 digests, then cons[n_slots], land[n_slots], claim[n_slots]
+#define RO_RING 0u       // 256 draws, k21 << 11 | 1: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
+#define RO_INIT 1024u    // 16 upcoming initial states (slot or -1)
+#define RO_LOG 1088u     // 16 x {cursor behind the accepted candidate, state left | done << 10}; reused as the prod scratch
+#define RO_POP 1216u     // 16 x candidates popped by the step (TRACE)
+#define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots], land[n_slots], claim[n_slots]
 
 typedef __attribute__((address_space(3))) volatile uint32_t ldsv_u32;
 typedef __attribute__((address_space(3))) volatile scan_u32x2 ldsv_u32x2;
@@ -56,14 +55,15 @@ typedef __attribute__((address_space(3))) volatile double ldsv_f64;
 #define LV32(a) (*(ldsv_u32 *)(a))
 #define LV64(a) (*(ldsv_u32x2 *)(a))
 
-__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 44u + 511u) & ~511u; }
+__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 44u + 1023u) & ~1023u; }
 
 // Per-wavefront landing area of the tick's global loads.  They are issued as LDS-DMA (global_load_lds_dword: no VGPR
 // destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
 enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_SLOTS };
-#define ROWS_DMA_BYTES 2560u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 512 (the rollout regions behind it stay 512-byte aligned)
+#define ROWS_DMA_BYTES 3072u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
+                              // the draw ring's address is formed with an OR)
 
 __device__ __forceinline__ uint32_t rows_bias(uint32_t dig) { return dig >= ROWS_BIAS ? dig - ROWS_BIAS : 0u; }
 
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256)
     const uint32_t li = lane & 15u, rw = lane >> 4, li4 = li * 4u;
     const uint32_t n_slots = (uint32_t)t.n_slots;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_byte *)lds_raw;
-    const uint32_t lds_pad = (0u - lds_base) & 511u;
+    const uint32_t lds_pad = (0u - lds_base) & 1023u;
     const uint32_t seg_a = lds_base + lds_pad;  // seg_off copy, shared by the block
     for (uint32_t i = threadIdx.x; i <= n_slots; i += blockDim.x) LV32(seg_a + i * 4u) = t.seg_off[i];
     const uint32_t rpb = blockDim.x >> 4;  // rollouts per block
@@ -127,16 +127,13 @@ __global__ void __launch_bounds__(256)
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
 
-    // Lanes 8..15 of a row look at the same window entries as lanes 0..7 but against the pad "draw" 0xffffffff, so they
-    // never hold the row's minimum; window stores are done by lanes 0..7 only.
-    const bool lower = li < 8u;
+    // Lanes 8..15 of a row are exact duplicates of lanes 0..7 inside the chain (same window entry, same draw, same key, same
+    // stores): the row minimum then needs only the three DPP steps that stay inside eight lanes, and nothing is predicated.
     const uint32_t li4w = (li & 7u) * 4u;
     const uint32_t win_rd_l = win_a + li4w;
-    const uint32_t rmask_l = lower ? (ROWS_RING * 4u - 4u) : 0u;
-    const uint32_t rbase_l = lower ? rbase + RO_RING : rbase + RO_PAD;
-    const uint32_t lifield = (li + 1u) << 28;
+    const uint32_t ring_a = rbase + RO_RING;
+    const uint32_t lifield = ((li & 7u) + 1u) << 28;
 
-    if (li == 8u) LV32(rbase + RO_PAD) = 0xffffffffu;
     __syncthreads();
     auto seg_at = [&](uint32_t s) -> uint32_t { return LV32(seg_a + s * 4u); };
 
@@ -177,7 +174,7 @@ __global__ void __launch_bounds__(256)
         gen += 16u;
     };
 #pragma unroll 1
-    for (int i = 0; i < 7; i++) gen16();  // 112 draws ahead
+    for (int i = 0; i < 15; i++) gen16();  // 240 draws ahead
 
     // ---- initial states: ring of the next 16 entries of the shuffled init queue (psrs.py:22-23, 32-37) ----
     uint32_t ic = ro.init_cursor[rr], ib = ic, ep = 0;
@@ -231,17 +228,16 @@ __global__ void __launch_bounds__(256)
         const uint32_t zz = dead ? 0u : z;
         vrow_w = win_a + zz * 32u;
         vcons = cons_a + zz * 4u;
-        const uint32_t ra = (((c << 2) + li4) & rmask_l) | rbase_l;
-        kt = LV32(ra);
         w = LV32(vrow_w + li4w);
         cz = LV32(vcons);
+        kt = LV32(ring_a + (((c << 2) + li4w) & (ROWS_RING * 4u - 4u)));
     };
     // the look of the hand-scheduled loop, restated for the iterations that run outside it (some row of the wavefront has
     // stopped, or TRACE): key as there, amb = some lane of the row needs the exact look
     auto look = [&](uint32_t &key, bool &amb) {
         const uint32_t d = w - kt;
         key = row_min16(kt > w ? 0xffffffffu : ((w & 0x7ffu) | lifield));
-        amb = row_min16(lower && d >= ROWS_AMB ? 0u : 1u) == 0u;
+        amb = row_min16(d >= ROWS_AMB ? 0u : 1u) == 0u;
     };
 
     // the step's bookkeeping for a clear accept of window entry k1-1 with payload `key`
@@ -258,7 +254,7 @@ __global__ void __launch_bounds__(256)
             pop_acc = 0;
         }
         const uint32_t k1x4 = k1 << 2;
-        if (lower) LV32(((li4 - k1x4) & 28u) | vrow_w) = li4 < k1x4 ? ROWS_EMPTY : w;
+        LV32(((li4w - k1x4) & 28u) | vrow_w) = li4w < k1x4 ? ROWS_EMPTY : w;  // (lanes 8..15 repeat the stores of lanes 0..7)
         z = key & 0x3ffu;
     };
 
@@ -346,7 +342,7 @@ __global__ void __launch_bounds__(256)
             if (TRACE) pop_acc += nrej;
             direct(it);
         }
-        while (!dead && gen - c < 48u) gen16();
+        while (!dead && gen - c < 136u) gen16();  // enough for the rest of the tick (15 looks of <= 8)
     };
 
 #ifdef OFFSIM_ROWS_PROF
@@ -518,7 +514,7 @@ __global__ void __launch_bounds__(256)
         PF_PH(6);
         if (!dead) {
             if (ic - ib >= 8u) load_init();
-            while (gen - c < 112u) gen16();
+            while (gen - c < 240u) gen16();
         }
         PF_PH(7);
     };
@@ -532,78 +528,84 @@ __global__ void __launch_bounds__(256)
     // Instruction order inside the loop: the draw of the NEXT look is requested as soon as the number of consumed candidates
     // is known (its ring address needs nothing else); the window entry and the cursor of the next state are requested
     // behind this step's three LDS stores (cursor, shifted row, log), because the next state may be this one.
-    uint32_t amb_lo = 0, amb_hi = 0;
     auto fast_run = [&](uint32_t &it, uint32_t &key) {
-        uint32_t c4 = (c << 2) + li4;                      // draw counter, as the byte offset of this lane's ring slot
-        const uint32_t lim4 = ((gen - 24u) << 2) + li4;    // c4 beyond this leaves fewer than 24 draws
+        uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
         uint32_t zz = z, logaddr = rbase + RO_LOG + it * 8u - 8u;
-        uint32_t k4, k1, d, tt, nrd;
-        uint64_t amb;
-        const uint64_t lowexec = 0x00ff00ff00ff00ffull;
+        uint32_t k4, d, tt, nrd, zn, cz1, vconsn;
+        uint64_t amb, self;
+        // One copy of the step; the loop body is four of them (the taken branch of the back edge is paid once per four steps).
+        // Ordering rule inside a copy: a VALU result is not consumed by the next instruction (a single wavefront pays ~2.6
+        // cycles for that), the three reads of the next look go out as early as their addresses exist, and the scalar
+        // event test comes late enough that the vector compares feeding it have long retired.
+#define ROWS_STEP                                                                                                        \
+            "s_waitcnt lgkmcnt(3)\n\t"                                   /* this look's entry, cursor and draw (the last step's three stores may be out) */ \
+            "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             /* (lane + 1) << 28 | done << 10 | z_next */ \
+            "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    /* borrow: not a clear accept */ \
+            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"                                                                     \
+            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"                                                               \
+            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
+            "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
+            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        /* 4 x candidates consumed by this step */     \
+            "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
+            "v_and_b32 %[zn], %[s7ff], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
+            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
+            "v_cmp_le_u32_e64 %[self], %[s400], %[zn]\n\t"               /* episode end, or the all-ones key of a row without a clear accept */ \
+            "v_cndmask_b32_e64 %[d], %[w], 0, vcc\n\t"                                                                    \
+            "ds_read_b32 %[w], %[nrd]\n\t"                               /* next look's entry, ahead of this step's stores (a self-loop leaves the loop) */ \
+            "v_cmp_eq_u32_e64 vcc, %[zn], %[zz]\n\t"                     /* next state == this state: the entry read above is stale */ \
+            "v_lshl_add_u32 %[vconsn], %[zn], 2, %[consa]\n\t"                                                            \
+            "v_lshrrev_b32 %[cz1], 28, %[key]\n\t"                                                                        \
+            "v_add_u32 %[c4], %[c4], %[k4]\n\t"                                                                           \
+            "v_add_u32 %[cz1], %[cz1], %[cz]\n\t"                         /* cursor behind the accepted candidate */     \
+            "ds_read_b32 %[cz], %[vconsn]\n\t"                           /* next state's cursor */                       \
+            "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
+            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
+            "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
+            "s_or_b64 %[amb], %[amb], %[self]\n\t"                                                                        \
+            "s_or_b64 %[amb], %[amb], vcc\n\t"                                                                            \
+            "s_cbranch_scc1 2f\n\t"                                                                                       \
+            /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
+            "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                           \
+            "ds_write2_b32 %[logaddr], %[cz1], %[zz] offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
+            "ds_write_b32 %[tt], %[d]\n\t"                                                                                \
+            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
+            "v_lshl_add_u32 %[vrow], %[zn], 5, %[wina]\n\t"                                                               \
+            "v_mov_b32 %[vcons], %[vconsn]\n\t"
         asm volatile(
             "1:\n\t"
-            "s_waitcnt lgkmcnt(1)\n\t"                                   // the draw and the window entry (the cursor may still be out)
-            "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    // borrow: not a clear accept
-            "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             // (lane + 1) << 28 | done << 10 | z_next
-            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 // the draw is above the entry by <= 17 units of T21: exact look
-            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"
-            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"
-            "s_and_b64 %[amb], %[amb], %[lowexec]\n\t"                  // (lanes 8..15 test the pad draw: meaningless)
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_min_u32_dpp %[key], %[key], %[key] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        // 4 x candidates consumed by this step
-            "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             // this lane's entry in the next state's row
-            "v_add_u32 %[c4], %[c4], %[k4]\n\t"
-            "v_and_or_b32 %[tt], %[c4], %[rmask], %[rbase]\n\t"
-            "ds_read_b32 %[kt], %[tt]\n\t"                               // next look's draw
-            "v_sub_u32 %[tt], %[lim4], %[c4]\n\t"                        // negative: draws run low
-            "v_and_b32 %[tt], %[ssign], %[tt]\n\t"
-            "v_and_or_b32 %[tt], %[key], %[s400], %[tt]\n\t"             // | episode end (also set in the all-ones key of a row without a clear accept)
-            "v_cmp_ne_u32_e32 vcc, 0, %[tt]\n\t"
-            "s_or_b64 vcc, vcc, %[amb]\n\t"
-            "s_cbranch_vccnz 2f\n\t"
-            // ---- no lane of the wavefront has an event: commit the step of all four rows ----
-            "v_lshrrev_b32 %[k1], 28, %[key]\n\t"
-            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               // slot (x4) of this lane's entry after the shift; borrow: it was consumed
-            "s_waitcnt lgkmcnt(1)\n\t"                                   // the cursor (only the draw requested above may be out)
-            "v_add_u32 %[cz], %[cz], %[k1]\n\t"
-            "v_cndmask_b32_e64 %[d], %[w], 0, vcc\n\t"
-            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"
-            "ds_write_b32 %[vcons], %[cz]\n\t"
-            "s_mov_b64 exec, %[lowexec]\n\t"
-            "ds_write_b32 %[tt], %[d]\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "ds_write2_b32 %[logaddr], %[cz], %[zz] offset1:1\n\t"      // {cursor behind the accepted candidate, state left}
-            "ds_read_b32 %[w], %[nrd]\n\t"
-            "v_and_b32 %[zz], 0x3ff, %[key]\n\t"
-            "v_lshl_add_u32 %[vcons], %[zz], 2, %[consa]\n\t"
-            "v_lshl_add_u32 %[vrow], %[zz], 5, %[wina]\n\t"
-            "ds_read_b32 %[cz], %[vcons]\n\t"
-            "s_add_u32 %[it], %[it], 1\n\t"
+            ROWS_STEP
+            "s_cmp_eq_u32 %[it], 16\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            ROWS_STEP
+            "s_cmp_eq_u32 %[it], 16\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            ROWS_STEP
+            "s_cmp_eq_u32 %[it], 16\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            ROWS_STEP
             "s_cmp_lt_u32 %[it], 16\n\t"
             "s_cbranch_scc1 1b\n\t"
-            "s_mov_b64 %[amb], 0\n\t"
+            "4:\n\t"
             "s_branch 3f\n\t"
             "2:\n\t"
             "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
+            "s_sub_u32 %[it], %[it], 1\n\t"
             "3:\n\t"
             "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
             : [w] "+v"(w), [kt] "+v"(kt), [cz] "+v"(cz), [c4] "+v"(c4), [vrow] "+v"(vrow_w), [vcons] "+v"(vcons), [zz] "+v"(zz),
-              [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [k1] "=&v"(k1), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
-              [amb] "=&s"(amb), [it] "+s"(it)
-            : [lif] "v"(lifield), [rmask] "v"(rmask_l), [rbase] "v"(rbase_l), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a),
-              [li4w] "v"(li4w), [lim4] "v"(lim4), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [ssign] "s"(0x80000000u),
-              [lowexec] "s"(lowexec)
-            : "vcc", "memory");
-        c = (c4 - li4) >> 2;
+              [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
+              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [amb] "=&s"(amb), [self] "=&s"(self), [it] "+s"(it)
+            : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a), [li4w] "v"(li4w),
+              [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [srmask] "s"(ROWS_RING * 4u - 4u)
+            : "vcc", "scc", "memory");
+#undef ROWS_STEP
+        c = (c4 - li4w) >> 2;
         z = zz;
-        amb_lo = (uint32_t)amb;
-        amb_hi = (uint32_t)(amb >> 32);
     };
 
     for (uint32_t drained = 0;;) {
@@ -618,7 +620,8 @@ __global__ void __launch_bounds__(256)
                 fast_run(it, key);
                 PF_ADD(pf_fast);
                 if (it == ROWS_TICK) break;
-                amb = (((rw & 2u) ? amb_hi : amb_lo) >> ((rw & 1u) * 16u) & 0xffffu) != 0u;
+                issue_reads();  // (the loop's early reads belonged to the next look)
+                look(key, amb);
             } else {
                 look(key, amb);
             }
