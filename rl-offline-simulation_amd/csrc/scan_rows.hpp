@@ -528,16 +528,21 @@ __global__ void __launch_bounds__(256)
     // Instruction order inside the loop: the draw of the NEXT look is requested as soon as the number of consumed candidates
     // is known (its ring address needs nothing else); the window entry and the cursor of the next state are requested
     // behind this step's three LDS stores (cursor, shifted row, log), because the next state may be this one.
-    auto fast_run = [&](uint32_t &it, uint32_t &key) {
+    // what the loop hands over when it is left for an event: the look's key, the lanes that need the exact look, and the
+    // stores of the step as the loop had prepared them (valid for the rows whose look was a clear accept)
+    uint32_t ex_key = 0, ex_d = 0, ex_slot = 0, ex_cz1 = 0, ex_k4 = 0;
+    uint64_t ex_amb = 0;
+    auto fast_run = [&](uint32_t &it) {
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
         uint32_t zz = z, logaddr = rbase + RO_LOG + it * 8u - 8u;
-        uint32_t k4, d, tt, nrd, zn, cz1, vconsn;
-        uint64_t amb, self;
+        uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn;
+        uint64_t amb, ev;
         // One copy of the step; the loop body is four of them (the taken branch of the back edge is paid once per four steps).
         // Ordering rule inside a copy: a VALU result is not consumed by the next instruction (a single wavefront pays ~2.6
-        // cycles for that), the three reads of the next look go out as early as their addresses exist, and the scalar
-        // event test comes late enough that the vector compares feeding it have long retired.
-#define ROWS_STEP                                                                                                        \
+        // cycles for that), the three reads of the next look go out as early as their addresses exist -- ahead of this
+        // step's stores; if the next state is this state (vcc) they are repeated behind the stores, out of line -- and the
+        // scalar event test comes late enough that the vector compares feeding it have long retired.
+#define ROWS_STEP(FIX, BACK)                                                                                              \
             "s_waitcnt lgkmcnt(3)\n\t"                                   /* this look's entry, cursor and draw (the last step's three stores may be out) */ \
             "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             /* (lane + 1) << 28 | done << 10 | z_next */ \
             "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    /* borrow: not a clear accept */ \
@@ -554,10 +559,10 @@ __global__ void __launch_bounds__(256)
             "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
             "v_and_b32 %[zn], %[s7ff], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
             "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
-            "v_cmp_le_u32_e64 %[self], %[s400], %[zn]\n\t"               /* episode end, or the all-ones key of a row without a clear accept */ \
+            "v_cmp_le_u32_e64 %[ev], %[s400], %[zn]\n\t"                 /* episode end, or the all-ones key of a row without a clear accept */ \
             "v_cndmask_b32_e64 %[d], %[w], 0, vcc\n\t"                                                                    \
-            "ds_read_b32 %[w], %[nrd]\n\t"                               /* next look's entry, ahead of this step's stores (a self-loop leaves the loop) */ \
-            "v_cmp_eq_u32_e64 vcc, %[zn], %[zz]\n\t"                     /* next state == this state: the entry read above is stale */ \
+            "ds_read_b32 %[w], %[nrd]\n\t"                               /* next look's entry */                         \
+            "v_cmp_eq_u32_e64 vcc, %[zn], %[zz]\n\t"                     /* next state == this state: the reads are repeated behind the stores */ \
             "v_lshl_add_u32 %[vconsn], %[zn], 2, %[consa]\n\t"                                                            \
             "v_lshrrev_b32 %[cz1], 28, %[key]\n\t"                                                                        \
             "v_add_u32 %[c4], %[c4], %[k4]\n\t"                                                                           \
@@ -566,32 +571,45 @@ __global__ void __launch_bounds__(256)
             "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
             "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
             "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
-            "s_or_b64 %[amb], %[amb], %[self]\n\t"                                                                        \
-            "s_or_b64 %[amb], %[amb], vcc\n\t"                                                                            \
+            "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
             "s_cbranch_scc1 2f\n\t"                                                                                       \
             /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
             "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                           \
             "ds_write2_b32 %[logaddr], %[cz1], %[zz] offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                \
+            "s_cmp_lg_u64 vcc, 0\n\t"                                                                                     \
             "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
             "v_lshl_add_u32 %[vrow], %[zn], 5, %[wina]\n\t"                                                               \
-            "v_mov_b32 %[vcons], %[vconsn]\n\t"
+            "v_mov_b32 %[vcons], %[vconsn]\n\t"                                                                           \
+            "s_cbranch_scc1 " FIX "f\n\t"                                                                                 \
+            BACK ":\n\t"
+#define ROWS_FIX(FIX, BACK)                                                                                               \
+            FIX ":\n\t"                                                   /* some row stays in its state: entry and cursor again, behind the stores */ \
+            "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                      \
+            "ds_read_b32 %[w], %[nrd]\n\t"                                                                                \
+            "ds_read_b32 %[cz], %[vcons]\n\t"                                                                             \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "s_branch " BACK "b\n\t"
         asm volatile(
             "1:\n\t"
-            ROWS_STEP
+            ROWS_STEP("51", "61")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP
+            ROWS_STEP("52", "62")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP
+            ROWS_STEP("53", "63")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP
+            ROWS_STEP("54", "64")
             "s_cmp_lt_u32 %[it], 16\n\t"
             "s_cbranch_scc1 1b\n\t"
             "4:\n\t"
             "s_branch 3f\n\t"
+            ROWS_FIX("51", "61")
+            ROWS_FIX("52", "62")
+            ROWS_FIX("53", "63")
+            ROWS_FIX("54", "64")
             "2:\n\t"
             "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
             "s_sub_u32 %[it], %[it], 1\n\t"
@@ -599,13 +617,53 @@ __global__ void __launch_bounds__(256)
             "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
             : [w] "+v"(w), [kt] "+v"(kt), [cz] "+v"(cz), [c4] "+v"(c4), [vrow] "+v"(vrow_w), [vcons] "+v"(vcons), [zz] "+v"(zz),
               [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
-              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [amb] "=&s"(amb), [self] "=&s"(self), [it] "+s"(it)
+              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
             : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a), [li4w] "v"(li4w),
               [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [srmask] "s"(ROWS_RING * 4u - 4u)
             : "vcc", "scc", "memory");
 #undef ROWS_STEP
+#undef ROWS_FIX
         c = (c4 - li4w) >> 2;
         z = zz;
+        ex_key = key;
+        ex_d = d;
+        ex_slot = tt;
+        ex_cz1 = cz1;
+        ex_k4 = k4;
+        ex_amb = amb;
+    };
+    // the iteration the loop was left in, from what it handed over (no second look, no re-read of the window)
+    auto resume_step = [&](uint32_t it) {
+        const uint32_t key = ex_key;
+        const bool amb = ((uint32_t)(ex_amb >> (rw * 16u)) & 0xffffu) != 0u;
+        if (key != 0xffffffffu && !amb) {  // clear accept: the stores the loop had prepared, then the episode end if that was the event
+            LV32(vcons) = ex_cz1;
+            scan_u32x2 e;
+            e.x = ex_cz1;
+            e.y = z | (key & 0x400u);
+            LV64(rbase + RO_LOG + it * 8u) = e;
+            LV32(ex_slot) = ex_d;
+            c += ex_k4 >> 2;
+            z = key & 0x3ffu;
+            if (key & 0x400u) {
+                ep++;
+                do_reset(it + 1u);
+            }
+        } else {
+            cz = ex_cz1 - (key >> 28);  // the cursor as it was before the look (the loop overwrote the register with its early read)
+            uint32_t nrej = 0;          // with a lane near a tie the exact look starts at the head of the queue
+            if (!amb) {                 // every candidate the window holds is a clear reject
+                const uint32_t v = LV32(land_a + z * 4u) - cz;
+                nrej = v < ROWS_W ? v : ROWS_W;
+                n_dry++;
+            } else {
+                n_tie++;
+            }
+            c += nrej;
+            cz += nrej;
+            direct(it);
+        }
+        while (!dead && gen - c < 136u) gen16();
     };
 
     for (uint32_t drained = 0;;) {
@@ -613,20 +671,20 @@ __global__ void __launch_bounds__(256)
         if (drained) it = ROWS_TICK;  // every row has stopped: only the reward pipeline is still draining
         while (it < ROWS_TICK) {
             issue_reads();
-            uint32_t key = 0;
-            bool amb = false;
             if (!TRACE && __ballot(dead != 0u) == 0ull) {
                 PF_START();
-                fast_run(it, key);
+                fast_run(it);
                 PF_ADD(pf_fast);
                 if (it == ROWS_TICK) break;
-                issue_reads();  // (the loop's early reads belonged to the next look)
-                look(key, amb);
+                PF_START();
+                resume_step(it);
             } else {
+                PF_START();
+                uint32_t key = 0;
+                bool amb = false;
                 look(key, amb);
+                if (!dead) slow_step(key, amb, it);
             }
-            PF_START();
-            if (!dead) slow_step(key, amb, it);
             it++;
             PF_ADD(pf_slow);
 #ifdef OFFSIM_ROWS_PROF
