@@ -1051,15 +1051,21 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
     const int rpb = waves * 4;
     const size_t lds = 1024 + seg_bytes + (size_t)waves * ROWS_DMA_BYTES + (size_t)rpb * region;
-    dim3 grid((unsigned)((ro->R + rpb - 1) / rpb)), block((unsigned)(waves * 64));
+    dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
+    // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
+    static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
     if (trace) {
-        HIP_TRY(allow_big_lds(k_eval_mc_rows<true>, 160 * 1024));
-        hipLaunchKernelGGL(k_eval_mc_rows<true>, grid, block, lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, n_gamma_pow, max_episodes, *out,
-                           seg_bytes, region);
-    } else {
-        HIP_TRY(allow_big_lds(k_eval_mc_rows<false>, 160 * 1024));
-        hipLaunchKernelGGL(k_eval_mc_rows<false>, grid, block, lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, n_gamma_pow, max_episodes, *out,
-                           seg_bytes, region);
+        HIP_TRY(allow_big_lds((k_eval_mc_rows<true, false>), 160 * 1024));
+        hipLaunchKernelGGL((k_eval_mc_rows<true, false>), grid, dim3((unsigned)(waves * 64)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
+    } else if (!helper) {
+        HIP_TRY(allow_big_lds((k_eval_mc_rows<false, false>), 160 * 1024));
+        hipLaunchKernelGGL((k_eval_mc_rows<false, false>), grid, dim3((unsigned)(waves * 64)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
+    } else {  // a helper wavefront per chain wavefront
+        HIP_TRY(allow_big_lds((k_eval_mc_rows<false, true>), 160 * 1024));
+        hipLaunchKernelGGL((k_eval_mc_rows<false, true>), grid, dim3((unsigned)(waves * 128)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
     }
     LAUNCH_CHECK();
     return OFFSIM_OK;

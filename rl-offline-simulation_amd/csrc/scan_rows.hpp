@@ -47,6 +47,10 @@ namespace offsim {
 #define RO_INIT 1024u    // 16 upcoming initial states (slot or -1)
 #define RO_LOG 1088u     // 16 x {cursor behind the accepted candidate, state left | done << 10}; reused as the prod scratch
 #define RO_POP 1216u     // 16 x candidates popped by the step (TRACE)
+#define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
+#define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
+enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24 };  // byte offsets in RO_SYNC
+#define ROWS_SPIN_LIMIT (1u << 22)  // polls (with s_sleep) before a hand-off wait gives up: ~2 s, never reached unless the protocol is broken
 #define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots], land[n_slots], claim[n_slots]
 
 typedef __attribute__((address_space(3))) volatile uint32_t ldsv_u32;
@@ -61,7 +65,7 @@ __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { ret
 // destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
-enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_SLOTS };
+enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */, DS_SLOTS = 11 };
 #define ROWS_DMA_BYTES 3072u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
                               // the draw ring's address is formed with an OR)
 
@@ -102,30 +106,49 @@ __device__ __noinline__ uint64_t rows_exact53(const uint64_t *__restrict__ rng4,
     return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
 }
 
-template <bool TRACE>
-__global__ void __launch_bounds__(256)
+// HELPER = false: one wavefront does everything for its four rollouts (also the TRACE build).
+// HELPER = true : the workgroup has a second set of wavefronts, one per chain wavefront and (by the dispatch order of a
+//   workgroup's waves) on the same SIMD: the helper owns the rejection stream (it fills the draw ring ahead of the chain) and
+//   the whole reward pipeline (row index -> reward -> in-order discounted sums), which the chain feeds through the step log.
+//   The chain keeps the look, the exact path and the window refill.  A single in-order wavefront retires an instruction per
+//   ~7 cycles here, so a SIMD has room for both, and the chain's timeline loses ~45 % of its instructions.
+//   Hand-off (all in the rollout's LDS region, RO_SYNC): the chain fills log buffer k & 1 during tick k, stores the step
+//   count and its draw counter, waits for its LDS stores (s_waitcnt lgkmcnt(0)) and only then stores SY_TICK = k + 1; the
+//   helper polls SY_TICK, reads the buffer, and stores SY_HTICK = k + 1 once its reads have returned (the chain does not
+//   reuse that buffer before).  Draws: the helper writes ring entries, waits, then stores SY_GEN; the chain never looks
+//   beyond the SY_GEN it has read, the helper never generates beyond SY_C + 240 of the 256 ring entries.  This relies on the
+//   LDS executing the DS instructions of ONE wavefront in issue order (data before flag); every wait is bounded
+//   (ROWS_SPIN_LIMIT) and ends the rollout with OFFSIM_ST_PROTOCOL instead of hanging the stream.
+template <bool TRACE, bool HELPER>
+__global__ void __launch_bounds__(HELPER ? 512 : 256)
     k_eval_mc_rows(offsim_table t, offsim_rollouts ro, offsim_streams sm, const uint64_t *__restrict__ keys, double gamma,
                    const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out,
                    uint32_t seg_bytes, uint32_t region_bytes) {
+    static_assert(!(TRACE && HELPER), "the TRACE build is the single-wavefront kernel");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_chain = HELPER ? (blockDim.x >> 7) : (blockDim.x >> 6);  // chain wavefronts of the workgroup
+    const bool is_helper = HELPER && wave_all >= n_chain;
+    const uint32_t wave = is_helper ? wave_all - n_chain : wave_all;  // the pair's index
     const uint32_t li = lane & 15u, rw = lane >> 4, li4 = li * 4u;
     const uint32_t n_slots = (uint32_t)t.n_slots;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_byte *)lds_raw;
     const uint32_t lds_pad = (0u - lds_base) & 1023u;
     const uint32_t seg_a = lds_base + lds_pad;  // seg_off copy, shared by the block
     for (uint32_t i = threadIdx.x; i <= n_slots; i += blockDim.x) LV32(seg_a + i * 4u) = t.seg_off[i];
-    const uint32_t rpb = blockDim.x >> 4;  // rollouts per block
+    const uint32_t rpb = n_chain * 4u;  // rollouts per block
     const uint32_t rid = wave * 4u + rw;
     const int64_t r = (int64_t)blockIdx.x * rpb + rid;
-    const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this wavefront's DMA slots
-    const uint32_t rbase = seg_a + seg_bytes + (blockDim.x >> 6) * ROWS_DMA_BYTES + rid * region_bytes;
+    const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this pair's DMA slots
+    const uint32_t rbase = seg_a + seg_bytes + n_chain * ROWS_DMA_BYTES + rid * region_bytes;
     auto dma_slot = [&](uint32_t slot) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
     const uint32_t win_a = rbase + RO_WIN, cons_a = win_a + n_slots * 32u, land_a = cons_a + n_slots * 4u, claim_a = land_a + n_slots * 4u;
+    const uint32_t sync_a = rbase + RO_SYNC;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
+    if (HELPER && !is_helper && li < 8u) LV32(sync_a + li4) = 0u;
 
     // Lanes 8..15 of a row are exact duplicates of lanes 0..7 inside the chain (same window entry, same draw, same key, same
     // stores): the row minimum then needs only the three DPP steps that stay inside eight lanes, and nothing is predicated.
@@ -148,6 +171,7 @@ __global__ void __launch_bounds__(256)
     const bool r64 = t.r_dtype == OFFSIM_F64;
 
     // ---- priming: every state's window holds the next 8 candidates of its queue ----
+    if (!is_helper)
     for (uint32_t s = li; s < n_slots; s += 16u) {
         const uint32_t c0 = cur_glb[s], beg = seg_at(s), len = seg_at(s + 1u) - beg;
         const uint32_t left = len - c0, want = left < ROWS_W ? left : ROWS_W;
@@ -159,22 +183,53 @@ __global__ void __launch_bounds__(256)
     }
 
     // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of k21 << 11 | 1 ----
-    U128 lane_state;
-    U128 plus16;
-    {
+    const bool owns_draws = HELPER ? is_helper : true;
+    U128 lane_state = u128(0, 0);
+    U128 plus16 = u128(0, 0);
+    if (owns_draws) {
         const U128 base = u128(rng4[0], rng4[1]), inc = u128(rng4[2], rng4[3]);
         plus16 = pcg_jump(inc, 16).plus;
         lane_state = pcg_apply(pcg_jump(inc, (uint64_t)li + 1), base);  // yields draw li
     }
     const U128 mult16 = u128(0xb6a4239f3b315f84ull, 0xf6ef6d3d288c03c1ull);  // PCG multiplier ** 16 mod 2**128
-    uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start (every examined candidate = one draw)
+    uint32_t gen = 0, c = 0;  // draws generated (HELPER chain: known to be generated) / consumed since kernel start
     auto gen16 = [&]() {
         LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = ((uint32_t)(pcg_output(lane_state) >> 43) << 11) | 1u;
         lane_state = add128(mul128(mult16, lane_state), plus16);
         gen += 16u;
     };
+    if (owns_draws) {
 #pragma unroll 1
-    for (int i = 0; i < 15; i++) gen16();  // 240 draws ahead
+        for (int i = 0; i < 15; i++) gen16();  // 240 draws ahead
+    }
+    // bounded wait of the hand-off protocol: polls `ready` until it holds; false if it gave up
+    auto spin_until = [&](auto ready) -> bool {
+        for (uint32_t n = 0; n < ROWS_SPIN_LIMIT; n++) {
+            if (ready()) return true;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        return false;
+    };
+    // HELPER chain: at least m draws beyond c are in the ring (published by the helper), or the rollout stops
+    int status = OFFSIM_ST_OK;
+    uint32_t nlog_dead = 0;  // steps the row logged in the tick it stopped in
+    auto need_draws = [&](uint32_t m, uint32_t logged) {
+        if (HELPER) {
+            if (gen - c >= m) return;
+            LV32(sync_a + SY_C) = c;  // the helper generates up to 240 beyond what it knows to be consumed
+            const bool ok = spin_until([&]() {
+                gen = LV32(sync_a + SY_GEN);
+                return gen - c >= m;
+            });
+            if (!ok) {
+                status = OFFSIM_ST_PROTOCOL;
+                dead = 1u;
+                nlog_dead = logged;
+            }
+        } else {
+            while (gen - c < m) gen16();
+        }
+    };
 
     // ---- initial states: ring of the next 16 entries of the shuffled init queue (psrs.py:22-23, 32-37) ----
     uint32_t ic = ro.init_cursor[rr], ib = ic, ep = 0;
@@ -185,12 +240,11 @@ __global__ void __launch_bounds__(256)
         if (k < N0) v = t.init_slot[init_row ? init_row[k] : k];
         LV32(rbase + RO_INIT + li4) = (uint32_t)v;
     };
-    load_init();
+    if (!is_helper) load_init();
 
     // ---- per-row state ----
+    uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
     uint32_t z = 0;  // current state slot
-    int status = OFFSIM_ST_OK;
-    uint32_t nlog_dead = 0;  // steps the row logged in the tick it stopped in
     uint32_t pop_acc = 0;    // candidates popped so far by the step in progress (TRACE)
     uint32_t n_dry = 0, n_tie = 0, n_tick = 0;
     // refill: one outstanding request per lane
@@ -248,7 +302,7 @@ __global__ void __launch_bounds__(256)
         scan_u32x2 e;
         e.x = cz1;
         e.y = z | (key & 0x400u);
-        LV64(rbase + RO_LOG + it * 8u) = e;
+        LV64(log_a + it * 8u) = e;
         if (TRACE) {
             LV32(rbase + RO_POP + it * 4u) = pop_acc + k1;
             pop_acc = 0;
@@ -277,7 +331,8 @@ __global__ void __launch_bounds__(256)
                 LV32(cons_a + z * 4u) = cz;
                 return;
             }
-            while (gen - c < 16u) gen16();
+            need_draws(16u, it);
+            if (dead) return;
             const uint32_t nv = rem < 16u ? rem : 16u;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
@@ -302,7 +357,7 @@ __global__ void __launch_bounds__(256)
             scan_u32x2 e;
             e.x = cz1;
             e.y = z | (acc & 0x400u);
-            LV64(rbase + RO_LOG + it * 8u) = e;
+            LV64(log_a + it * 8u) = e;
             if (TRACE) {
                 LV32(rbase + RO_POP + it * 4u) = pop_acc + k1;
                 pop_acc = 0;
@@ -342,7 +397,7 @@ __global__ void __launch_bounds__(256)
             if (TRACE) pop_acc += nrej;
             direct(it);
         }
-        while (!dead && gen - c < 136u) gen16();  // enough for the rest of the tick (15 looks of <= 8)
+        if (!dead) need_draws(136u, it + 1u);  // enough for the rest of the tick (15 looks of <= 8)
     };
 
 #ifdef OFFSIM_ROWS_PROF
@@ -355,86 +410,38 @@ __global__ void __launch_bounds__(256)
 #define PF_START()
 #define PF_ADD(x)
 #endif
-    // ---- once per 16 iterations; lane = step of the tick ----
-    auto tick = [&]() {
-#ifdef OFFSIM_ROWS_PROF
-        pf_t1 = __builtin_amdgcn_s_memtime();
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
-        PF_PH(0);
-        const uint32_t n = dead ? nlog_dead : ROWS_TICK;
-        nlog_dead = 0;
-        n_tick++;
-        const scan_u32x2 le = LV64(rbase + RO_LOG + li * 8u);
+    // ---- reward pipeline, three ticks deep so that no tick waits on HBM; lane = step of the tick.  R1 (tick k): request the
+    // local row (loc stream) and the discount factor of the steps of tick k; R2 (k+1): request their rewards; R3 (k+2): the
+    // in-order discounted sums (bit-exact Gs).  Runs in the chain wavefront's tick, or in the helper wavefront (HELPER).
+    auto rewards = [&](uint32_t n, scan_u32x2 le, uint32_t pop_i) {
         const bool mine = li < n;
         const uint32_t s_i = le.y & 0x3ffu, pos_i = le.x - 1u;
         const bool done_i = mine && (le.y & 0x400u);
-        uint32_t pop_i = 0;
-        if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
-        // everything the previous tick's loads brought, before the slots are reused
-        const uint32_t in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
         const uint32_t in_loc = dma_slot(DS_LOC), in_gplo = dma_slot(DS_GPLO), in_gphi = dma_slot(DS_GPHI);
         const uint32_t in_rlo = dma_slot(DS_RLO), in_rhi = dma_slot(DS_RHI);
-
-        PF_PH(1);
-        // C: land the digests requested one tick ago.  Entries are appended only at the window's current end: whatever a
-        // direct read has covered meanwhile is skipped, whatever does not fit is requested again later.
-        if (rq_n) {
-            const uint32_t cs = LV32(cons_a + rq_s * 4u);
-            uint32_t ld = LV32(land_a + rq_s * 4u);
-            const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
-#pragma unroll
-            for (uint32_t e = 0; e < 4u; e++) {
-                if (e < rq_n && rq_p + e == ld && ld - cs < ROWS_W) {
-                    LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = rows_bias(dd[e]);
-                    ld++;
-                }
-            }
-            LV32(land_a + rq_s * 4u) = ld;
-            rq_n = 0;
-        }
-        PF_PH(2);
-        // A: one request per state left in this tick (the lane that logged the step tops the state up)
-        if (mine) LV32(claim_a + s_i * 4u) = li;
-        if (mine && LV32(claim_a + s_i * 4u) == li) {
-            const uint32_t cs = LV32(cons_a + s_i * 4u), ld = LV32(land_a + s_i * 4u);
-            const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
-            const uint32_t have = ld - cs, room = have < ROWS_W ? ROWS_W - have : 0u, left = len - ld;
-            uint32_t want = room < left ? room : left;
-            want = want < 4u ? want : 4u;
-            if (want) {
-                const uint32_t *src = dbase + beg + ld;
-                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
-                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
-                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
-                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
-                rq_s = s_i;
-                rq_p = ld;
-                rq_n = want;
-            }
-        }
-
         PF_PH(3);
         // R3: in-order discounted-return accumulation (psrs.py:262-269) for the steps of two ticks ago: the products are
-        // broadcast through LDS, every lane of the row runs the same sequential sum (bit-exact Gs)
+        // broadcast through LDS, every lane of the row runs the same sequential sum
         {
             double rv = 0.0;
             if (li < n2) rv = r64 ? __hiloint2double((int)in_rhi, (int)in_rlo) : (double)__uint_as_float(in_rlo);
             const double prod = li < n2 ? gp2 * rv : 0.0;  // product first, then the running sum in step order (+0.0 changes nothing)
-            *(ldsv_f64 *)(rbase + RO_LOG + li * 8u) = prod;
+            const uint32_t pa = dma_a + DS_PROD * 256u + rw * 128u;
+            *(ldsv_f64 *)(pa + li * 8u) = prod;
             double p[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) p[i] = *(ldsv_f64 *)(rbase + RO_LOG + (uint32_t)i * 8u);
+            for (int i = 0; i < 16; i++) p[i] = *(ldsv_f64 *)(pa + (uint32_t)i * 8u);
             int32_t base_len = (int32_t)len_acc;  // length of the open episode minus the steps of this tick already counted
-            if (any2 == 0ull) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) G = G + p[i];
-            } else {
+            for (int q = 0; q < 4; q++) {
+                if (((any2 >> (4 * q)) & 0xfull) == 0ull) {  // (wave-uniform) no row ends an episode in these four steps
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    G = G + p[i];
-                    if ((any2 >> i) & 1ull) {      // (wave-uniform) some row ends an episode at step i
-                        if ((dm2 >> i) & 1u) {     // this row does (psrs.py:265-269)
+                    for (int i = 4 * q; i < 4 * q + 4; i++) G = G + p[i];
+                } else {
+#pragma unroll
+                    for (int i = 4 * q; i < 4 * q + 4; i++) {
+                        G = G + p[i];
+                        if ((dm2 >> i) & 1u) {  // this row ends an episode at step i (psrs.py:265-269)
                             if (li == 0u) {
                                 if (out.ep_g && (int64_t)ep_acc < out.ep_cap) out.ep_g[r * out.ep_cap + ep_acc] = G;
                                 if (out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = base_len + i + 1;
@@ -512,11 +519,151 @@ __global__ void __launch_bounds__(256)
             steps += n;
         }
         PF_PH(6);
-        if (!dead) {
-            if (ic - ib >= 8u) load_init();
-            while (gen - c < 240u) gen16();
+    };
+
+    // ================================================ the helper wavefront (HELPER) ================================================
+    if (is_helper) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LV32(sync_a + SY_GEN) = gen;  // the first 240 draws are in the ring
+        uint32_t fin = 0;
+        for (uint32_t k = 0;; k++) {
+            // wait for the chain to publish tick k; meanwhile keep the ring topped up (the chain may run short inside a tick)
+            uint32_t cp = 0;
+            bool ok = false;
+            for (uint32_t tries = 0; tries < ROWS_SPIN_LIMIT; tries++) {
+                const uint32_t tk = LV32(sync_a + SY_TICK);
+                cp = LV32(sync_a + SY_C);
+                if (gen - cp < 240u) {
+                    while (gen - cp < 240u) gen16();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring entries first, then the count
+                    LV32(sync_a + SY_GEN) = gen;
+                }
+                if (__ballot(tk <= k) == 0ull) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads of the previous tick
+            const uint32_t la = rbase + ((k & 1u) ? RO_LOG2 : RO_LOG);
+            const uint32_t n = LV32(sync_a + ((k & 1u) ? SY_N1 : SY_N0));
+            const scan_u32x2 le = LV64(la + li * 8u);
+            fin = LV32(sync_a + SY_FIN);
+            cp = LV32(sync_a + SY_C);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned: the chain may reuse the buffer
+            LV32(sync_a + SY_HTICK) = k + 1u;
+            rewards(n, le, 0u);
+            if (gen - cp < 240u) {
+                while (gen - cp < 240u) gen16();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                LV32(sync_a + SY_GEN) = gen;
+            }
+            if (__ballot(fin == 0u) == 0ull) break;  // every rollout of the wavefront has stopped: tick k was the last one
         }
-        PF_PH(7);
+        scan_u32x2 none;
+        none.x = 0;
+        none.y = 0;
+        for (int dr = 0; dr < 2; dr++) {  // drain the pipeline (R2, R3 of the last ticks)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rewards(0u, none, 0u);
+        }
+        if (fin == (uint32_t)OFFSIM_ST_EXHAUSTED + 1u) {  // psrs.py:265: the cut-short episode still logs its length
+            if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
+            n_len++;
+        }
+        if (li == 0u && r < (int64_t)ro.R) {
+            out.sum_g[r] = sum_g;
+            out.n_ep[r] = ep_acc;
+            out.n_len[r] = n_len;
+        }
+        return;
+    }
+
+    // ---- the chain wavefront's tick, once per 16 iterations; lane = step of the tick ----
+    uint32_t tick_k = 0;
+    auto tick = [&]() {
+#ifdef OFFSIM_ROWS_PROF
+        pf_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t n = dead ? nlog_dead : ROWS_TICK;
+        nlog_dead = 0;
+        n_tick++;
+        if (HELPER) {  // hand the tick's log to the helper: data, then (behind a wait) the flag
+            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
+            LV32(sync_a + SY_C) = c;
+            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LV32(sync_a + SY_TICK) = tick_k + 1u;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
+        PF_PH(0);
+        const scan_u32x2 le = LV64(log_a + li * 8u);
+        const bool mine = li < n;
+        const uint32_t s_i = le.y & 0x3ffu;
+        uint32_t pop_i = 0;
+        if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
+        const uint32_t in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+        PF_PH(1);
+        // C: land the digests requested one tick ago.  Entries are appended only at the window's current end: whatever a
+        // direct read has covered meanwhile is skipped, whatever does not fit is requested again later.
+        if (rq_n) {
+            const uint32_t cs = LV32(cons_a + rq_s * 4u);
+            uint32_t ld = LV32(land_a + rq_s * 4u);
+            const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; e++) {
+                if (e < rq_n && rq_p + e == ld && ld - cs < ROWS_W) {
+                    LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = rows_bias(dd[e]);
+                    ld++;
+                }
+            }
+            LV32(land_a + rq_s * 4u) = ld;
+            rq_n = 0;
+        }
+        PF_PH(2);
+        // A: one request per state left in this tick (the lane that logged the step tops the state up)
+        if (mine) LV32(claim_a + s_i * 4u) = li;
+        if (mine && LV32(claim_a + s_i * 4u) == li) {
+            const uint32_t cs = LV32(cons_a + s_i * 4u), ld = LV32(land_a + s_i * 4u);
+            const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
+            const uint32_t have = ld - cs, room = have < ROWS_W ? ROWS_W - have : 0u, left = len - ld;
+            uint32_t want = room < left ? room : left;
+            want = want < 4u ? want : 4u;
+            if (want) {
+                const uint32_t *src = dbase + beg + ld;
+                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
+                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
+                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
+                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
+                rq_s = s_i;
+                rq_p = ld;
+                rq_n = want;
+            }
+        }
+        if (HELPER) {
+            steps += n;
+            tick_k++;
+            log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
+            if (!dead) {
+                if (ic - ib >= 8u) load_init();
+                // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
+                const uint32_t want_h = tick_k - 1u;
+                if (!spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
+                    status = OFFSIM_ST_PROTOCOL;
+                    dead = 1u;
+                }
+                if (!dead) need_draws(136u, 0u);
+            }
+            PF_PH(7);
+        } else {
+            rewards(n, le, pop_i);
+            if (!dead) {
+                if (ic - ib >= 8u) load_init();
+                while (gen - c < 240u) gen16();
+            }
+            PF_PH(7);
+        }
     };
 
     // ---- the chain ----
@@ -534,7 +681,7 @@ __global__ void __launch_bounds__(256)
     uint64_t ex_amb = 0;
     auto fast_run = [&](uint32_t &it) {
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
-        uint32_t zz = z, logaddr = rbase + RO_LOG + it * 8u - 8u;
+        uint32_t zz = z, logaddr = log_a + it * 8u - 8u;
         uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn;
         uint64_t amb, ev;
         // One copy of the step; the loop body is four of them (the taken branch of the back edge is paid once per four steps).
@@ -641,7 +788,7 @@ __global__ void __launch_bounds__(256)
             scan_u32x2 e;
             e.x = ex_cz1;
             e.y = z | (key & 0x400u);
-            LV64(rbase + RO_LOG + it * 8u) = e;
+            LV64(log_a + it * 8u) = e;
             LV32(ex_slot) = ex_d;
             c += ex_k4 >> 2;
             z = key & 0x3ffu;
@@ -663,9 +810,10 @@ __global__ void __launch_bounds__(256)
             cz += nrej;
             direct(it);
         }
-        while (!dead && gen - c < 136u) gen16();
+        if (!dead) need_draws(136u, it + 1u);
     };
 
+    if (!dead) need_draws(136u, 0u);  // (HELPER: the helper wavefront has filled the ring)
     for (uint32_t drained = 0;;) {
         uint32_t it = 0;
         if (drained) it = ROWS_TICK;  // every row has stopped: only the reward pipeline is still draining
@@ -694,9 +842,9 @@ __global__ void __launch_bounds__(256)
         PF_START();
         tick();
         PF_ADD(pf_tick);
-        if (__ballot(!dead) == 0ull && ++drained == 3u) break;  // two more ticks drain the reward pipeline (R2, R3)
+        if (__ballot(!dead) == 0ull && (HELPER || ++drained == 3u)) break;  // (single wavefront: two more ticks drain the reward pipeline)
     }
-    if (status == OFFSIM_ST_EXHAUSTED) {  // psrs.py:265: the cut-short episode still logs its length
+    if (!HELPER && status == OFFSIM_ST_EXHAUSTED) {  // psrs.py:265: the cut-short episode still logs its length
         if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
         n_len++;
     }
@@ -712,11 +860,13 @@ __global__ void __launch_bounds__(256)
                 ro.rng[4 * r + 0] = nb.hi;
                 ro.rng[4 * r + 1] = nb.lo;
             }
-            out.sum_g[r] = sum_g;
-            out.n_ep[r] = ep_acc;
+            if (!HELPER) {  // (HELPER: the helper wavefront owns the sums and writes them)
+                out.sum_g[r] = sum_g;
+                out.n_ep[r] = ep_acc;
+                out.n_len[r] = n_len;
+            }
             out.steps[r] = steps;
             out.cand[r] = c;
-            out.n_len[r] = n_len;
             out.status[r] = status;
 #ifdef OFFSIM_ROWS_PROF
             if (out.dbg) {
