@@ -49,7 +49,8 @@ namespace offsim {
 #define RO_POP 1216u     // 16 x candidates popped by the step (TRACE)
 #define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
 #define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
-enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24 };  // byte offsets in RO_SYNC
+enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24,  // byte offsets in RO_SYNC
+       SY_INITP = 32, SY_LEFT = 36 };  // chain loop: LDS address of the row's next initial state, episode ends it may still serve itself
 #define ROWS_SPIN_LIMIT (1u << 22)  // polls (with s_sleep) before a hand-off wait gives up: ~2 s, never reached unless the protocol is broken
 #define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots], land[n_slots], claim[n_slots]
 
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (TRACE) pop_acc += nrej;
             direct(it);
         }
-        if (!dead) need_draws(136u, it + 1u);  // enough for the rest of the tick (15 looks of <= 8)
+        if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);  // enough for the rest of the tick (looks of <= 8)
     };
 
 #ifdef OFFSIM_ROWS_PROF
@@ -653,7 +654,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                     status = OFFSIM_ST_PROTOCOL;
                     dead = 1u;
                 }
-                if (!dead) need_draws(136u, 0u);
+                if (!dead) {
+                    gen = LV32(sync_a + SY_GEN);
+                    need_draws(136u, 0u);
+                }
             }
             PF_PH(7);
         } else {
@@ -680,6 +684,17 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     uint32_t ex_key = 0, ex_d = 0, ex_slot = 0, ex_cz1 = 0, ex_k4 = 0;
     uint64_t ex_amb = 0;
     auto fast_run = [&](uint32_t &it) {
+        // episode ends the loop may serve itself: after this many the episode cap, the end of the init queue or the end of
+        // the 16-entry ring is reached and the C++ path has to look
+        const uint32_t initp0 = rbase + RO_INIT + ((ic - ib) << 2);
+        {
+            uint32_t left = 16u - (ic - ib);
+            left = left < N0 - ic ? left : N0 - ic;  // (ic <= N0)
+            const uint32_t cap = ep + 1u < max_episodes ? max_episodes - ep - 1u : 0u;
+            left = left < cap ? left : cap;
+            LV32(sync_a + SY_INITP) = initp0;
+            LV32(sync_a + SY_LEFT) = left;
+        }
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
         uint32_t zz = z, logaddr = log_a + it * 8u - 8u;
         uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn;
@@ -689,7 +704,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         // cycles for that), the three reads of the next look go out as early as their addresses exist -- ahead of this
         // step's stores; if the next state is this state (vcc) they are repeated behind the stores, out of line -- and the
         // scalar event test comes late enough that the vector compares feeding it have long retired.
-#define ROWS_STEP(FIX, BACK)                                                                                              \
+#define ROWS_STEP(FIX, EPI, BACK)                                                                                              \
             "s_waitcnt lgkmcnt(3)\n\t"                                   /* this look's entry, cursor and draw (the last step's three stores may be out) */ \
             "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             /* (lane + 1) << 28 | done << 10 | z_next */ \
             "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    /* borrow: not a clear accept */ \
@@ -719,7 +734,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
             "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
             "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
-            "s_cbranch_scc1 2f\n\t"                                                                                       \
+            "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
             /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
             "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                           \
             "ds_write2_b32 %[logaddr], %[cz1], %[zz] offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
@@ -730,6 +745,45 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_mov_b32 %[vcons], %[vconsn]\n\t"                                                                           \
             "s_cbranch_scc1 " FIX "f\n\t"                                                                                 \
             BACK ":\n\t"
+        /* Out of line: the only event of the look is the end of an episode in some rows (psrs.py:249-269: env.reset() pops */   \
+        /* the shuffled init queue).  The row's next initial states wait in its LDS ring; SY_LEFT says how many the loop may */  \
+        /* take before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed with */ \
+        /* the log word marked "done", the next state of those rows is their next initial state. */                           \
+#define ROWS_EPI(EPI, BACK)                                                                                               \
+            EPI ":\n\t"                                                                                                    \
+            "s_cmp_lg_u64 %[amb], 0\n\t"                                                                                   \
+            "s_cbranch_scc1 2f\n\t"                                     /* a lane needs the exact look */                  \
+            "v_cmp_le_u32_e32 vcc, 0x500, %[zn]\n\t"                    /* all-ones key: a row without a clear accept */   \
+            "s_cbranch_vccnz 2f\n\t"                                                                                       \
+            "v_cmp_le_u32_e32 vcc, 0x400, %[zn]\n\t"                    /* vcc: the rows whose episode ends */             \
+            "ds_read_b32 %[w], %[rsync] offset:36\n\t"                  /* (w and cz are free: their early reads are repeated below) */ \
+            "ds_read_b32 %[cz], %[rsync] offset:32\n\t"                                                                    \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+            "v_cmp_eq_u32_e64 %[ev], 0, %[w]\n\t"                                                                          \
+            "s_and_b64 %[ev], %[ev], vcc\n\t"                                                                              \
+            "s_cbranch_scc1 2f\n\t"                                     /* a row may not take another reset here */       \
+            "ds_read_b32 %[vconsn], %[cz]\n\t"                          /* the next initial state */                      \
+            "v_subrev_u32 %[w], 1, %[w]\n\t"                                                                               \
+            "v_add_u32 %[cz], 4, %[cz]\n\t"                                                                                \
+            "v_or_b32 %[nrd], 0x400, %[zz]\n\t"                         /* log word of an episode end */                  \
+            "s_mov_b64 exec, vcc\n\t"                                                                                      \
+            "ds_write_b32 %[rsync], %[w] offset:36\n\t"                                                                    \
+            "ds_write_b32 %[rsync], %[cz] offset:32\n\t"                                                                   \
+            "s_mov_b64 exec, -1\n\t"                                                                                       \
+            "v_cndmask_b32_e32 %[nrd], %[zz], %[nrd], vcc\n\t"                                                             \
+            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
+            "v_cndmask_b32_e32 %[zn], %[zn], %[vconsn], vcc\n\t"                                                           \
+            "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                            \
+            "ds_write2_b32 %[logaddr], %[cz1], %[nrd] offset1:1\n\t"                                                       \
+            "ds_write_b32 %[tt], %[d]\n\t"                                                                                 \
+            "v_lshl_add_u32 %[vcons], %[zn], 2, %[consa]\n\t"                                                              \
+            "v_lshl_add_u32 %[vrow], %[zn], 5, %[wina]\n\t"                                                                \
+            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                   \
+            "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                       \
+            "ds_read_b32 %[w], %[nrd]\n\t"                                                                                 \
+            "ds_read_b32 %[cz], %[vcons]\n\t"                                                                              \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+            "s_branch " BACK "b\n\t"
 #define ROWS_FIX(FIX, BACK)                                                                                               \
             FIX ":\n\t"                                                   /* some row stays in its state: entry and cursor again, behind the stores */ \
             "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                      \
@@ -739,16 +793,16 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_branch " BACK "b\n\t"
         asm volatile(
             "1:\n\t"
-            ROWS_STEP("51", "61")
+            ROWS_STEP("51", "71", "61")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("52", "62")
+            ROWS_STEP("52", "72", "62")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("53", "63")
+            ROWS_STEP("53", "73", "63")
             "s_cmp_eq_u32 %[it], 16\n\t"
             "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("54", "64")
+            ROWS_STEP("54", "74", "64")
             "s_cmp_lt_u32 %[it], 16\n\t"
             "s_cbranch_scc1 1b\n\t"
             "4:\n\t"
@@ -757,6 +811,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             ROWS_FIX("52", "62")
             ROWS_FIX("53", "63")
             ROWS_FIX("54", "64")
+            ROWS_EPI("71", "61")
+            ROWS_EPI("72", "62")
+            ROWS_EPI("73", "63")
+            ROWS_EPI("74", "64")
             "2:\n\t"
             "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
             "s_sub_u32 %[it], %[it], 1\n\t"
@@ -766,12 +824,18 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
               [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
               [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
             : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a), [li4w] "v"(li4w),
-              [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [srmask] "s"(ROWS_RING * 4u - 4u)
+              [rsync] "v"(sync_a), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [srmask] "s"(ROWS_RING * 4u - 4u)
             : "vcc", "scc", "memory");
 #undef ROWS_STEP
 #undef ROWS_FIX
+#undef ROWS_EPI
         c = (c4 - li4w) >> 2;
         z = zz;
+        {
+            const uint32_t served = (LV32(sync_a + SY_INITP) - initp0) >> 2;  // episode ends the loop served
+            ic += served;
+            ep += served;
+        }
         ex_key = key;
         ex_d = d;
         ex_slot = tt;
@@ -810,7 +874,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             cz += nrej;
             direct(it);
         }
-        if (!dead) need_draws(136u, it + 1u);
+        if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);
     };
 
     if (!dead) need_draws(136u, 0u);  // (HELPER: the helper wavefront has filled the ring)
