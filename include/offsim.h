@@ -51,7 +51,8 @@ extern "C" {
 #define OFFSIM_ST_NO_INIT 2     /* PSRS.reset returned None: init queue empty                       */
 #define OFFSIM_ST_KEYERROR 3    /* current state never occurs as a from-state (psrs.py:44)          */
 #define OFFSIM_ST_INACTIVE 4    /* rollout had no current state (s is None); nothing done           */
-#define OFFSIM_ST_PROTOCOL 5    /* internal: a bounded wait of the two-wavefront scan expired (never expected) */
+#define OFFSIM_ST_PROTOCOL 5    /* internal: a bounded wait between the two wavefronts of offsim_eval_mc_streams expired
+                                   (never expected; the rollout stops instead of hanging the stream) */
 
 /* The logged-transition table, SoA, rows physically grouped by from-state (CSR).  Built by
  * offsim_group_by_state + offsim_table_gather from the OfflineDataset.experience arrays
@@ -215,12 +216,7 @@ int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi,
  * with per-state candidate windows in LDS; n_slots <= 256, otherwise OFFSIM_EUNSUPPORTED (use offsim_eval_mc). */
 int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream);
 /* Name of the kernel offsim_eval_mc_keys launches for this state count and R rollouts ("" if it would refuse): measurement
- * code labels its roofline with it.  Two bit-identical kernels exist: k_eval_mc_win (one wavefront per rollout; the default)
- * and k_eval_mc_split (chain + helper wavefront per rollout, picked for 256..3072 rollouts where it is 9-17 % faster).  The
- * split kernel's two wavefronts exchange a log ring and counters through plain LDS words: it relies on the LDS unit executing
- * one wavefront's DS instructions in issue order (so data written before a counter is visible before the counter); its waits
- * are bounded and a stalled protocol ends the rollout with OFFSIM_ST_PROTOCOL instead of hanging the stream.
- * OFFSIM_SCAN_SPLIT=0/1 in the environment forces a variant. */
+ * code labels its roofline with it. */
 const char *offsim_eval_mc_keys_kernel(int32_t n_slots, int32_t R);
 int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
                         const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,

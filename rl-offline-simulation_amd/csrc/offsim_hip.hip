@@ -915,7 +915,6 @@ extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const 
 // Fast evalMC scan: compiled-policy keys + LDS candidate windows (scan_win.hpp)
 // ------------------------------------------------------------------------------------------------
 #include "scan_win.hpp"
-#include "scan_split.hpp"
 
 extern "C" int offsim_compile_policy(const offsim_table *t, const double *pi, uint64_t *keys_out, void *stream) {
     int rc = check_table(t);
@@ -933,18 +932,11 @@ extern "C" int offsim_compile_policy(const offsim_table *t, const double *pi, ui
     return OFFSIM_OK;
 }
 
-// Which of the two scan kernels serves R rollouts (both are bit-identical; the parity suite runs against each):
-// the one-wavefront kernel k_eval_mc_win is the default -- R = 1 drop-in calls, small batches, and the headline size, where the
-// CU is at its instruction-issue ceiling; the two-wavefront kernel (scan_split.hpp: chain wave + helper wave per rollout) takes
-// the sizes where it is measurably faster, 256..3072 rollouts per GPU (17 % at <= 1024, 9 % at 3072, 7 % slower at 4096).
-// OFFSIM_SCAN_SPLIT=0/1 forces a variant.
-static bool scan_uses_split(int32_t R) {
-    static const int split_mode = getenv("OFFSIM_SCAN_SPLIT") ? atoi(getenv("OFFSIM_SCAN_SPLIT")) : -1;
-    return split_mode == 1 || (split_mode < 0 && R >= 256 && R <= 3072);
-}
+// Name of the kernel offsim_eval_mc_keys launches (measurement label).  (Round 1 also had a two-wavefront variant of this
+// kernel; the row-packed scan of scan_rows.hpp, with its helper wavefronts, has taken its place.)
 extern "C" const char *offsim_eval_mc_keys_kernel(int32_t n_slots, int32_t R) {
-    if (n_slots > 256) return "";
-    return scan_uses_split(R) ? "k_eval_mc_split" : "k_eval_mc_win";
+    (void)R;
+    return n_slots > 256 ? "" : "k_eval_mc_win";
 }
 
 extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64_t *keys, double gamma,
@@ -975,32 +967,6 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
                                n_gamma_pow, max_episodes, *out);                                                      \
     } while (0)
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS
-    const bool split = scan_uses_split(ro->R);
-    if (split) {
-#define LAUNCH_SPLIT(W, ROUNDS)                                                                                       \
-    do {                                                                                                              \
-        const size_t region = (OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 +             \
-                               (trace ? split_log_bytes<W, true>() : split_log_bytes<W, false>()) + 511) & ~(size_t)511; \
-        const size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) + 4 * region;                   \
-        dim3 grid2((ro->R + 3) / 4), block2(512);                                                                     \
-        if (trace) {                                                                                                  \
-            HIP_TRY(allow_big_lds((k_eval_mc_split<W, ROUNDS, true>), 160 * 1024)); \
-            hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, true>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
-                               n_gamma_pow, max_episodes, *out);                                                      \
-        } else {                                                                                                      \
-            HIP_TRY(allow_big_lds((k_eval_mc_split<W, ROUNDS, false>), 160 * 1024)); \
-            hipLaunchKernelGGL((k_eval_mc_split<W, ROUNDS, false>), grid2, block2, lds, st, *t, *ro, keys, gamma, gamma_pow, \
-                               n_gamma_pow, max_episodes, *out);                                                      \
-        }                                                                                                             \
-    } while (0)
-        if (rounds == 1) LAUNCH_SPLIT(32, 1);
-        else if (rounds == 2) LAUNCH_SPLIT(8, 2);
-        else if (rounds == 3) LAUNCH_SPLIT(8, 3);
-        else LAUNCH_SPLIT(8, 4);
-#undef LAUNCH_SPLIT
-        LAUNCH_CHECK();
-        return OFFSIM_OK;
-    }
     if (rounds == 1) LAUNCH_WIN(32, 1);
     else if (rounds == 2) LAUNCH_WIN(8, 2);
     else if (rounds == 3) LAUNCH_WIN(8, 3);

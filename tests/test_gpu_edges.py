@@ -156,17 +156,22 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
             assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
 
 
-@pytest.mark.parametrize("variant", ["win", "split"])
+@pytest.mark.parametrize("variant", ["rows_single", "win"])
 def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
-    """The fast path of eval_mc has three bit-identical kernels: csrc/scan_rows.hpp (four rollouts per wavefront, candidate
-    streams: the default wherever it applies, so the whole in-process suite runs on it), csrc/scan_win.hpp (one wavefront per
-    rollout) and csrc/scan_split.hpp (chain + helper wavefront).  OFFSIM_SCAN_ROWS=0 takes the first out of the choice and
-    OFFSIM_SCAN_SPLIT=0/1 forces one of the others; both are read per process: the golden-fixture parity tests, the config
-    tests and the edge cases of this file run again in a child process for each."""
+    """The fast path of eval_mc has three bit-identical forms: csrc/scan_rows.hpp with a helper wavefront per chain wavefront
+    (four rollouts per wavefront, candidate streams: the default wherever it applies, so the whole in-process suite runs on
+    it), the same kernel as a single wavefront (OFFSIM_ROWS_HELPER=0; also what every call with trace outputs runs), and
+    csrc/scan_win.hpp on queue permutations (OFFSIM_SCAN_ROWS=0).  The switches are read per process: the golden-fixture
+    parity tests, the config tests, the round-2 tests and the edge cases of this file run again in a child process for each."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, OFFSIM_SCAN_ROWS="0", OFFSIM_SCAN_SPLIT="1" if variant == "split" else "0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_configs.py"),
-                        os.path.join(here, "test_gpu_edges.py"), "-m", "gpu", "-x", "-q", "-k", "not every_scan_variant"],
+    env = dict(os.environ)
+    if variant == "win":
+        env["OFFSIM_SCAN_ROWS"] = "0"
+    else:
+        env["OFFSIM_ROWS_HELPER"] = "0"
+    files = ["test_gpu_parity.py", "test_gpu_configs.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant != "win" else [])
+    r = subprocess.run([sys.executable, "-m", "pytest"] + [os.path.join(here, f) for f in files] +
+                       ["-m", "gpu", "-x", "-q", "-k", "not every_scan_variant and not headline_table_size and not two_ranks"],
                        env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -92,6 +92,12 @@ def test_golden_case(name, fast, gpu):
             assert np.array_equal(o["ep_len"][i, :nl].cpu().numpy(), d[f"s{s}_mc_lengths"])
             if ne:
                 assert abs(float(o["sum_g"][i]) / ne - float(d[f"s{s}_mc_mean"])) <= 1e-5  # north_star tolerance
+        if fast:  # the same evaluation without trace outputs: the hand-scheduled chain loop and its helper wavefronts
+            reset_sampler()
+            o2 = env.eval_mc(table.policy_slots(pi), float(d["gamma"]), ep_cap=table.N0 + 1, fast=fast)
+            torch.cuda.synchronize()
+            for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status", "ep_g", "ep_len"):
+                assert torch.equal(o[k], o2[k]), k
 
 
 STEP_CASES = [c for c in PSRS_CASES if "p_new_step" in load(c).files and load(c)["in_z"].shape[0] <= 5000]
