@@ -120,7 +120,7 @@ def oracle_for(e):
     return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
 
 
-def parity_check(base, pi, gamma, seeds, got):
+def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_seed=1234):
     """The oracle on a few seeds of the SAME table the timed passes ran on (one rollout per host thread), against what the
     GPU returned for those seeds: accepted steps, candidates examined and completed episodes equal, value estimate
     within 1e-5 (BASELINE.json north_star)."""
@@ -129,7 +129,11 @@ def parity_check(base, pi, gamma, seeds, got):
 
     def work(k):
         o = base.clone()
-        o.reset_sampler(int(seeds[k]))
+        if shuffle == "shared":  # one queue order for all rollouts, per-rollout rejection streams (psrs.py:20 is a plain attribute)
+            o.reset_sampler(int(shuffle_seed))
+            o.set_rejection_seed(int(seeds[k]))
+        else:
+            o.reset_sampler(int(seeds[k]))
         res[k] = o.evalmc(10 ** 9, pi, gamma)
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(len(seeds))]
@@ -422,11 +426,11 @@ def run(a):
         if extra:
             out["rollout_sharded"] = extra
         base = None
-        if not a.no_parity_check:
+        if not a.no_parity_check and a.shuffle != "table_order":  # (the reference has no unshuffled mode to compare with)
             base = oracle_for(e)
             ps = [s for s in PARITY_SEEDS if s < R]
             got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ps}
-            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got)
+            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got, a.shuffle, 1234)
             if not out["parity_check"]["ok"]:
                 sys.stderr.write(json.dumps(out["parity_check"]) + "\n")
                 raise SystemExit("bench.py: the GPU results differ from the oracle on this table -- no number is reported")
