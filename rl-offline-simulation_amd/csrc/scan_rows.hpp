@@ -49,7 +49,7 @@ namespace offsim {
 #define RO_POP 1216u     // 16 x candidates popped by the step (TRACE)
 #define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
 #define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
-enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24,  // byte offsets in RO_SYNC
+enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24, SY_REQ = 28,  // byte offsets in RO_SYNC
        SY_INITP = 32, SY_LEFT = 36 };  // chain loop: LDS address of the row's next initial state, episode ends it may still serve itself
 #define ROWS_SPIN_LIMIT (1u << 22)  // polls (with s_sleep) before a hand-off wait gives up: ~2 s, never reached unless the protocol is broken
 #define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots], land[n_slots], claim[n_slots]
@@ -66,7 +66,8 @@ __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { ret
 // destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
-enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */, DS_SLOTS = 11 };
+enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */,
+       DS_RQD = 11 /* HELPER: the request each lane made (position | state << 17 | entries << 27) */, DS_SLOTS = 12 };
 #define ROWS_DMA_BYTES 3072u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
                               // the draw ring's address is formed with an OR)
 
@@ -414,11 +415,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // ---- reward pipeline, three ticks deep so that no tick waits on HBM; lane = step of the tick.  R1 (tick k): request the
     // local row (loc stream) and the discount factor of the steps of tick k; R2 (k+1): request their rewards; R3 (k+2): the
     // in-order discounted sums (bit-exact Gs).  Runs in the chain wavefront's tick, or in the helper wavefront (HELPER).
-    auto rewards = [&](uint32_t n, scan_u32x2 le, uint32_t pop_i) {
-        const bool mine = li < n;
-        const uint32_t s_i = le.y & 0x3ffu, pos_i = le.x - 1u;
-        const bool done_i = mine && (le.y & 0x400u);
-        const uint32_t in_loc = dma_slot(DS_LOC), in_gplo = dma_slot(DS_GPLO), in_gphi = dma_slot(DS_GPHI);
+    uint32_t in_loc = 0, in_gplo = 0, in_gphi = 0;
+    // first half: what the previous tick's loads brought, and R3 (no new load is issued here)
+    auto rewards_a = [&]() {
+        in_loc = dma_slot(DS_LOC);
+        in_gplo = dma_slot(DS_GPLO);
+        in_gphi = dma_slot(DS_GPHI);
         const uint32_t in_rlo = dma_slot(DS_RLO), in_rhi = dma_slot(DS_RHI);
         PF_PH(3);
         // R3: in-order discounted-return accumulation (psrs.py:262-269) for the steps of two ticks ago: the products are
@@ -459,6 +461,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             len_acc = (uint32_t)(base_len + (int32_t)n2);
         }
         PF_PH(4);
+    };
+    // second half: R2 and R1 issue this tick's loads
+    auto rewards_b = [&](uint32_t n, scan_u32x2 le, uint32_t pop_i) {
+        const bool mine = li < n;
+        const uint32_t s_i = le.y & 0x3ffu, pos_i = le.x - 1u;
+        const bool done_i = mine && (le.y & 0x400u);
         // R2: rewards of the steps of one tick ago (row = segment start + local row, the latter from the loc stream)
         {
             if (li < n1) {
@@ -522,6 +530,30 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         PF_PH(6);
     };
 
+    // A: one request per state left in the tick (the lane that holds the step tops the state up): up to four entries behind the
+    // window's end, as LDS-DMA into this pair's RQ slots.  Returns what it asked for (0 = nothing).
+    auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) {
+        q_n = 0;
+        if (mine) LV32(claim_a + s_i * 4u) = li;
+        if (mine && LV32(claim_a + s_i * 4u) == li) {
+            const uint32_t cs = LV32(cons_a + s_i * 4u), ld = LV32(land_a + s_i * 4u);
+            const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
+            const uint32_t have = ld - cs, room = have < ROWS_W ? ROWS_W - have : 0u, left = len - ld;
+            uint32_t want = room < left ? room : left;
+            want = want < 4u ? want : 4u;
+            if (want) {
+                const uint32_t *src = dbase + beg + ld;
+                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
+                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
+                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
+                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
+                q_s = s_i;
+                q_p = ld;
+                q_n = want;
+            }
+        }
+    };
+
     // ================================================ the helper wavefront (HELPER) ================================================
     if (is_helper) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -554,7 +586,15 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             cp = LV32(sync_a + SY_C);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned: the chain may reuse the buffer
             LV32(sync_a + SY_HTICK) = k + 1u;
-            rewards(n, le, 0u);
+            {   // the window top-ups this tick's steps call for; the chain lands them at the end of its next tick
+                uint32_t q_s = 0, q_p = 0, q_n = 0;
+                request(li < n, le.y & 0x3ffu, q_s, q_p, q_n);
+                LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
+            }
+            rewards_a();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the requested digests (issued ~one R3 ago) and their descriptors are in LDS
+            LV32(sync_a + SY_REQ) = k + 1u;
+            rewards_b(n, le, 0u);
             if (gen - cp < 240u) {
                 while (gen - cp < 240u) gen16();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -567,7 +607,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         none.y = 0;
         for (int dr = 0; dr < 2; dr++) {  // drain the pipeline (R2, R3 of the last ticks)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            rewards(0u, none, 0u);
+            rewards_a();
+            rewards_b(0u, none, 0u);
         }
         if (fin == (uint32_t)OFFSIM_ST_EXHAUSTED + 1u) {  // psrs.py:265: the cut-short episode still logs its length
             if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
@@ -590,24 +631,30 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t n = dead ? nlog_dead : ROWS_TICK;
         nlog_dead = 0;
         n_tick++;
-        if (HELPER) {  // hand the tick's log to the helper: data, then (behind a wait) the flag
-            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
-            LV32(sync_a + SY_C) = c;
-            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            LV32(sync_a + SY_TICK) = tick_k + 1u;
+        if (HELPER) {
+            // the helper has made the requests of the PREVIOUS tick's steps (while this tick ran); their digests are in the RQ slots
+            if (tick_k >= 1u) {
+                const uint32_t want_r = tick_k;
+                if (!spin_until([&]() { return LV32(sync_a + SY_REQ) >= want_r; }) && !dead) {
+                    status = OFFSIM_ST_PROTOCOL;
+                    dead = 1u;
+                }
+                const uint32_t dsc = dma_slot(DS_RQD);
+                rq_p = dsc & 0x1ffffu;
+                rq_s = (dsc >> 17) & 0x3ffu;
+                rq_n = dsc >> 27;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
         PF_PH(0);
         const scan_u32x2 le = LV64(log_a + li * 8u);
-        const bool mine = li < n;
-        const uint32_t s_i = le.y & 0x3ffu;
         uint32_t pop_i = 0;
         if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
         const uint32_t in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
         PF_PH(1);
-        // C: land the digests requested one tick ago.  Entries are appended only at the window's current end: whatever a
-        // direct read has covered meanwhile is skipped, whatever does not fit is requested again later.
+        // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
+        // covered meanwhile is skipped, whatever does not fit is requested again later.
         if (rq_n) {
             const uint32_t cs = LV32(cons_a + rq_s * 4u);
             uint32_t ld = LV32(land_a + rq_s * 4u);
@@ -623,26 +670,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             rq_n = 0;
         }
         PF_PH(2);
-        // A: one request per state left in this tick (the lane that logged the step tops the state up)
-        if (mine) LV32(claim_a + s_i * 4u) = li;
-        if (mine && LV32(claim_a + s_i * 4u) == li) {
-            const uint32_t cs = LV32(cons_a + s_i * 4u), ld = LV32(land_a + s_i * 4u);
-            const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
-            const uint32_t have = ld - cs, room = have < ROWS_W ? ROWS_W - have : 0u, left = len - ld;
-            uint32_t want = room < left ? room : left;
-            want = want < 4u ? want : 4u;
-            if (want) {
-                const uint32_t *src = dbase + beg + ld;
-                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
-                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
-                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
-                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
-                rq_s = s_i;
-                rq_p = ld;
-                rq_n = want;
-            }
-        }
         if (HELPER) {
+            // hand the tick's log to the helper: data, then (behind a wait) the flag
+            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
+            LV32(sync_a + SY_C) = c;
+            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LV32(sync_a + SY_TICK) = tick_k + 1u;
             steps += n;
             tick_k++;
             log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
@@ -661,7 +695,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
             PF_PH(7);
         } else {
-            rewards(n, le, pop_i);
+            request(li < n, le.y & 0x3ffu, rq_s, rq_p, rq_n);
+            rewards_a();
+            rewards_b(n, le, pop_i);
             if (!dead) {
                 if (ic - ib >= 8u) load_init();
                 while (gen - c < 240u) gen16();
