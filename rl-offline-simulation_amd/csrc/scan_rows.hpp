@@ -344,15 +344,15 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 const uint32_t lc = lbase ? (uint32_t)lbase[beg + cz + li] : cz + li;
                 ok = !(rows_exact53(rng4, (uint64_t)c + li + 1u) > key_T(keys[beg + lc]));
             }
-            const uint32_t f = row_min16(ok ? li : 16u);
-            if (f == 16u) {  // all of them rejected: consumed (one draw each)
+            const uint32_t fk = row_min16(ok ? ((li << 11) | (dg & 0x7ffu)) : 0xffffffffu);  // first accepted lane and its done / z_next
+            if (fk == 0xffffffffu) {  // all of them rejected: consumed (one draw each)
                 c += nv;
                 cz += nv;
                 if (TRACE) pop_acc += nv;
                 continue;
             }
-            const uint32_t acc = row_min16(li == f ? dg : 0xffffffffu);  // the accepted candidate's digest
-            const uint32_t k1 = f + 1u;
+            const uint32_t acc = fk & 0x7ffu;
+            const uint32_t k1 = (fk >> 11) + 1u;
             c += k1;
             const uint32_t cz1 = cz + k1;
             LV32(cons_a + z * 4u) = cz1;
@@ -898,16 +898,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
         } else {
             cz = ex_cz1 - (key >> 28);  // the cursor as it was before the look (the loop overwrote the register with its early read)
-            uint32_t nrej = 0;          // with a lane near a tie the exact look starts at the head of the queue
-            if (!amb) {                 // every candidate the window holds is a clear reject
-                const uint32_t v = LV32(land_a + z * 4u) - cz;
-                nrej = v < ROWS_W ? v : ROWS_W;
-                n_dry++;
-            } else {
-                n_tie++;
-            }
-            c += nrej;
-            cz += nrej;
+            if (amb) n_tie++;           // exact look from the head of the queue: what the window rejected is rejected again, with the same draws
+            else n_dry++;
             direct(it);
         }
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);
