@@ -196,12 +196,20 @@ int offsim_step_exo(const offsim_table *ts, const offsim_table *tx, offsim_rollo
 #define OFFSIM_TD_NONE 0
 #define OFFSIM_TD_QLEARN 1
 #define OFFSIM_TD_EXPSARSA 2
+/* behaviour policy of the learner drivers: the fixed tabular `pi`, or epsilon-greedy on the rollout's own Q table
+ * (offsim4rl/agents/tabular.py:24-32, what qlearn_psrs is normally run with, psrs.py:158): before every step
+ * p_new = epsilon / nA everywhere and 1 - epsilon + epsilon / nA at argmax_a Q[S,a].  Ties take the FIRST maximum (the
+ * reference draws among them from the global NumPy stream, which no caller can reproduce). */
+#define OFFSIM_BEHAVIOUR_FIXED 0
+#define OFFSIM_BEHAVIOUR_EPS_GREEDY 1
 typedef struct offsim_td {
     int32_t mode;
     double alpha;
     double *q;
     double *td_err;
     int64_t td_cap;
+    int32_t behaviour; /* OFFSIM_BEHAVIOUR_* */
+    double epsilon;    /* OFFSIM_BEHAVIOUR_EPS_GREEDY */
 } offsim_td;
 int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const double *pi, int32_t reject_mode, double gamma,
                    const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,

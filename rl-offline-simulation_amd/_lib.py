@@ -45,10 +45,11 @@ class Streams(C.Structure):
 
 class TD(C.Structure):
     """struct offsim_td"""
-    _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64)]
+    _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64), ("behaviour", _i32), ("epsilon", C.c_double)]
 
 
 TD_QLEARN, TD_EXPSARSA = 1, 2
+BEHAVIOUR_FIXED, BEHAVIOUR_EPS_GREEDY = 0, 1
 
 # name -> (restype, argtypes): exactly the entry points include/offsim.h declares
 SIGNATURES = {

@@ -570,6 +570,8 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     PROB *pi_lds = (PROB *)((double *)(tables + waves * (WAVE + 1)) + (TD ? (size_t)waves * n_slots * nA : 0));
     uint32_t *seg_lds = (uint32_t *)(pi_lds + (size_t)n_slots * nA);
     uint32_t *cur_lds = seg_lds + (n_slots + 1) + (size_t)wave * n_slots;
+    // TD with an epsilon-greedy behaviour policy: this rollout's action distribution in its current state, rebuilt from its Q row before every step
+    double *beh_lds = (double *)(((uintptr_t)(seg_lds + (n_slots + 1) + (size_t)waves * n_slots) + 7) & ~(uintptr_t)7) + (size_t)wave * nA;
     for (int i = threadIdx.x; i < n_slots * nA; i += blockDim.x) pi_lds[i] = pi[i];
     for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg_lds[i] = t.seg_off[i];
     __syncthreads();
@@ -610,8 +612,20 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
         bool done = false;
         while (!done) {
             const double gp = discount_at(gamma_pow, (uint64_t)n_gamma_pow, gamma, (uint64_t)tt);  // issued ahead of the step
-            StepResult s = psrs_step<PL, PROB>(t, seg_lds, perm_row, slot, cur_lds, pi_lds + (size_t)slot * nA, reject_mode, 0u,
-                                               rng, consumed);
+            const PROB *p_step = pi_lds + (size_t)slot * nA;
+            if (TD && td.behaviour == OFFSIM_BEHAVIOUR_EPS_GREEDY) {
+                // epsilon_greedy_policy(Q[[S]], epsilon) (offsim4rl/agents/tabular.py:24-32): epsilon / nA everywhere, 1 - epsilon + epsilon / nA
+                // at the maximum of the Q row (the first one: the reference breaks ties with the global NumPy stream)
+                const double *qs = q_lds + (size_t)slot * nA;
+                int best = 0;
+                for (int k = 1; k < nA; k++) best = qs[k] > qs[best] ? k : best;
+                const double lo = td.epsilon / (double)nA, hi = 1.0 - td.epsilon + lo;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                for (int k = lane; k < nA; k += WAVE) beh_lds[k] = k == best ? hi : lo;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                p_step = (const PROB *)beh_lds;
+            }
+            StepResult s = psrs_step<PL, PROB>(t, seg_lds, perm_row, slot, cur_lds, p_step, reject_mode, 0u, rng, consumed);
             cand += s.popped;
             if (s.status != OFFSIM_ST_OK) {  // :257-259 (None) or KeyError
                 status = s.status;
@@ -683,7 +697,7 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
 
 static size_t evalmc_lds_bytes(int waves, int n_slots, int nA, size_t prob_bytes, bool td = false) {
     return (size_t)waves * (WAVE + 1) * sizeof(Jump) + (td ? (size_t)waves * n_slots * nA * 8 : 0) + (size_t)n_slots * nA * prob_bytes +
-           (size_t)(n_slots + 1) * 4 + (size_t)waves * n_slots * 4;
+           (size_t)(n_slots + 1) * 4 + (size_t)waves * n_slots * 4 + (td ? 8 + (size_t)waves * nA * 8 : 0);
 }
 
 static int check_table(const offsim_table *t) {
@@ -888,6 +902,7 @@ extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const 
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_td: required output is NULL%s");
     if ((td->mode != OFFSIM_TD_QLEARN && td->mode != OFFSIM_TD_EXPSARSA) || !td->q) return fail(OFFSIM_EINVAL, "eval_td: bad td mode or NULL q%s");
+    if (td->behaviour != OFFSIM_BEHAVIOUR_FIXED && td->behaviour != OFFSIM_BEHAVIOUR_EPS_GREEDY) return fail(OFFSIM_EINVAL, "eval_td: bad behaviour%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_td: gamma_pow is NULL%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;

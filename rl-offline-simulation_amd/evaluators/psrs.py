@@ -294,9 +294,12 @@ class BatchedPSRS:
         return o
 
     # -- qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with a Q-independent behaviour policy, all rollouts in one launch --
-    def eval_td(self, pi_slots, gamma, mode, alpha, q_slots=None, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096):
+    def eval_td(self, pi_slots, gamma, mode, alpha, q_slots=None, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096,
+                behaviour=L.BEHAVIOUR_FIXED, epsilon=0.0):
         """mode: _lib.TD_QLEARN | _lib.TD_EXPSARSA.  q_slots [R,n_slots,nA] f64 (Q_init; zeros if None) is updated in place
-        and returned as out["q"]; out["td_err"] [R,trace_cap] holds the TD errors in step order."""
+        and returned as out["q"]; out["td_err"] [R,trace_cap] holds the TD errors in step order.
+        behaviour = _lib.BEHAVIOUR_EPS_GREEDY: every rollout acts epsilon-greedily on its own Q table (the learner-in-the-loop
+        case of psrs.py:158); pi_slots is then only the target policy of expected SARSA."""
         t, dev, R = self.table, self.table.device, self.R
         pi_d = torch.as_tensor(np.ascontiguousarray(pi_slots), dtype=torch.float64).to(dev).reshape(t.n_slots, t.nA).contiguous()
         if n_episodes is None:
@@ -316,7 +319,8 @@ class BatchedPSRS:
         oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")), ep_len=L.ptr(o.get("ep_len")),
                          ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")), trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
-        tdc = L.TD(mode=mode, alpha=float(alpha), q=L.ptr(q), td_err=L.ptr(o.get("td_err")), td_cap=trace_cap)
+        tdc = L.TD(mode=mode, alpha=float(alpha), q=L.ptr(q), td_err=L.ptr(o.get("td_err")), td_cap=trace_cap, behaviour=int(behaviour),
+                   epsilon=float(epsilon))
         L.check(L.load().offsim_eval_td(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), self.reject_mode, float(gamma), L.ptr(gp),
                                         gp.numel(), int(n_episodes), C.byref(oc), C.byref(tdc), L.stream_ptr()))
         o["q"] = q
@@ -601,13 +605,68 @@ def _fixed_behaviour(behavior_policy, nA, epsilon):
     return outs[0] if all(np.array_equal(outs[0], o) for o in outs[1:]) else None
 
 
-def _td_device(env, n_episodes, p_rows, gamma, alpha, mode, Q_init):
+def _eps_greedy_behaviour(behavior_policy, nA, epsilon):
+    """True if behavior_policy(Q, {'epsilon': e}) is epsilon_greedy_policy of offsim4rl/agents/tabular.py:24-32: e / nA everywhere
+    and 1 - e + e / nA at the maximum of each row (probed on rows without ties)."""
+    if nA < 2:
+        return False
+    g = np.random.default_rng(1)
+    lo, hi = np.ones(1)[0] * epsilon / nA, 1 - epsilon + epsilon / nA
+    state = np.random.get_state()  # the reference's _random_argmax draws from the global stream even without a tie
+    try:
+        for _ in range(4):
+            q = g.permutation(nA).astype(float)[None, :] + g.random((1, nA)) * 0.5
+            want = np.full((1, nA), lo)
+            want[0, int(np.argmax(q[0]))] = hi
+            if not np.array_equal(np.asarray(behavior_policy(q, dict(epsilon=epsilon))), want):
+                return False
+    except Exception:
+        return False
+    finally:
+        np.random.set_state(state)
+    return True
+
+
+class _ReplayedMemory:
+    """The `memory` list of qlearn_psrs for the device path with an epsilon-greedy learner: the behaviour distribution of
+    every step depends on Q at that step, so the tuples are rebuilt by replaying the TD updates over the accepted rows on first use."""
+
+    def __init__(self, env, rows, Q0, gamma, alpha, epsilon):
+        self._args, self._items = (env, rows, Q0, gamma, alpha, epsilon), None
+
+    def _build(self):
+        if self._items is None:
+            env, rows, Q0, gamma, alpha, epsilon = self._args
+            Q = Q0.copy()
+            nA = Q.shape[1]
+            lo, hi = epsilon / nA, 1 - epsilon + epsilon / nA
+            items = []
+            for r in rows:
+                S, A, R, S_ = int(env._z[r]), env._a_of(r), env._r[r], int(env._zn[r])
+                p = np.full(nA, lo)
+                p[int(np.argmax(Q[S]))] = hi
+                items.append((env._obs[r], A, R, env._next_obs[r], bool(env._done[r]), p, {"z": S, "a": A, "p": env._p_of(r)}))
+                Q[S, A] = Q[S, A] + alpha * (R + gamma * Q[S_].max() - Q[S, A])
+            self._items = items
+        return self._items
+
+    def __len__(self):
+        return len(self._args[1])
+
+    def __iter__(self):
+        return iter(self._build())
+
+    def __getitem__(self, i):
+        return self._build()[i]
+
+
+def _td_device(env, n_episodes, p_rows, gamma, alpha, mode, Q_init, behaviour=L.BEHAVIOUR_FIXED, epsilon=0.0):
     t = env.table
     nS, nA = env.nS, env.nA
     Q0 = np.zeros((nS, nA)) if Q_init is None else np.asarray(Q_init).copy().astype(float)
     n_ep = int(min(n_episodes, t.N0 + 1))
     o = env._env.eval_td(t.policy_slots(p_rows), gamma, mode, alpha, q_slots=_q_to_slots(t, Q0)[None], n_episodes=n_ep,
-                         ep_cap=n_ep + 1, trace_cap=t.N + 1)
+                         ep_cap=n_ep + 1, trace_cap=t.N + 1, behaviour=behaviour, epsilon=epsilon)
     status = int(o["status"].cpu()[0])
     if status == L.ST_KEYERROR:
         raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
@@ -624,11 +683,20 @@ def _memory(env, rows, p_of_state):
 
 
 def qlearn_psrs(env, n_episodes, behavior_policy, gamma, alpha=0.1, epsilon=1.0, Q_init=None, save_Q=0):
-    """psrs.py:119-185.  With a Q-independent behaviour policy (epsilon = 1, uniform, ...) on a device-backed PSRS the whole
-    loop -- PSRS steps and Q-learning updates -- is one kernel launch; otherwise the reference's host loop drives env.step."""
+    """psrs.py:119-185.  On a device-backed PSRS the whole loop -- PSRS steps and Q-learning updates -- is one kernel launch
+    when the behaviour policy is Q-independent (epsilon = 1, uniform, ...) or the reference's epsilon_greedy_policy with a
+    constant epsilon; otherwise the reference's host loop drives env.step."""
     fixed = None
-    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not callable(epsilon) and not save_Q:
+    on_device = isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not callable(epsilon) and not save_Q
+    if on_device:
         fixed = _fixed_behaviour(behavior_policy, env.nA, epsilon)
+    if on_device and fixed is None and _eps_greedy_behaviour(behavior_policy, env.nA, epsilon):
+        # the learner acts epsilon-greedily on the Q table it is learning: p_new is rebuilt from the rollout's Q row (in LDS) before
+        # every step.  Ties between maximal Q values go to the first action (the reference draws among them from np.random).
+        t = env.table
+        p_rows = np.full((max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1), env.nA), 1.0 / env.nA)
+        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, p_rows, gamma, alpha, L.TD_QLEARN, Q_init, L.BEHAVIOUR_EPS_GREEDY, epsilon)
+        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "TD_errors": td, "memory": _ReplayedMemory(env, rows, Q0, gamma, alpha, epsilon)}
     if fixed is not None:
         t = env.table
         p_rows = np.tile(np.asarray(fixed, dtype=np.float64), (max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1), 1))

@@ -292,6 +292,20 @@ def main():
             Q, info = ref_psrs.expSARSA_psrs(h.env, 10 ** 9, pi_t, gam, alpha=0.1)
             out[f"s{s}_es_Q"], out[f"s{s}_es_Gs"] = Q, info["Gs"]
             out[f"s{s}_es_rows"] = np.array([r for r in h.rows if r >= 0], np.int64)
+            # the learner-in-the-loop case proper: epsilon-greedy on the learner's own Q (psrs.py:158, agents/tabular.py:24-32).
+            # Q_init has no equal entries and the updates keep it that way here, so _random_argmax never has a tie to break
+            # with the global NumPy stream (checked below by running twice with different np.random seeds).
+            for eps in (0.1, 0.5):
+                res = []
+                for np_seed in (1, 2):
+                    np.random.seed(np_seed)
+                    h.env.reset_sampler(seed=s)
+                    h.clear()
+                    Q, info = ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.epsilon_greedy_policy, gam, alpha=0.1, epsilon=eps, Q_init=Qi)
+                    res.append((Q, info["Gs"], info["TD_errors"], np.array([r for r in h.rows if r >= 0], np.int64)))
+                assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1])), "a tie was broken by the global stream"
+                tag = f"s{s}_qe{int(eps * 10)}"
+                out[tag + "_Q"], out[tag + "_Gs"], out[tag + "_td"], out[tag + "_rows"] = res[0]
         np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
         print(f"{nm:28s} N={len(inp['z']):6d}")
 

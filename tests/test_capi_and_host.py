@@ -47,6 +47,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Table) == 8 + 4 * 4 + 7 * 8 + 8 + 2 * 8 + 2 * 8  # ... + max_seg, min_seg
     assert ctypes.sizeof(_lib.Rollouts) == 8 + 4 * 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.EvalMCOut) == 13 * 8
+    assert ctypes.sizeof(_lib.TD) == 8 + 8 + 8 + 8 + 8 + 8 + 8 and ctypes.sizeof(_lib.Streams) == 4 * 8
 
 
 def test_no_cpu_fallback():

@@ -157,6 +157,25 @@ def test_td_drivers_golden(name, gpu):
         assert np.abs(Q - d[f"s{s}_es_Q"]).max() <= 1e-12
         assert np.array_equal(info["Gs"], d[f"s{s}_es_Gs"])
         assert len(info["memory"]) == len(d[f"s{s}_es_rows"])
+        # the learner acting epsilon-greedily on its own Q (psrs.py:158 with agents/tabular.py:24-32), on the device
+        def eps_greedy(Q, args):  # the reference's epsilon_greedy_policy (ties cannot occur in these fixtures)
+            pi = np.ones_like(Q) * args["epsilon"] / Q.shape[1]
+            for r_, a_ in enumerate(np.argmax(Q, axis=1)):
+                pi[r_, a_] = 1 - args["epsilon"] + args["epsilon"] / Q.shape[1]
+            return pi
+        for eps in (0.1, 0.5):
+            tag = f"s{s}_qe{int(eps * 10)}"
+            env.reset_sampler(s)
+            Q, info = qlearn_psrs(env, 10 ** 9, eps_greedy, float(d["gamma"]), alpha=float(d["alpha"]), epsilon=eps, Q_init=d["Q_init"])
+            assert type(info["memory"]).__name__ == "_ReplayedMemory"  # (the device path was taken)
+            assert np.array_equal(Q, d[tag + "_Q"])
+            assert np.array_equal(info["Gs"], d[tag + "_Gs"])
+            assert np.array_equal(info["TD_errors"], d[tag + "_td"])
+            assert [int(m[6]["a"]) for m in info["memory"]] == [int(d["in_a"][r]) for r in d[tag + "_rows"]]
+            env.reset_sampler(s)
+            Qh, info_h = qlearn_psrs(env, 10 ** 9, eps_greedy, float(d["gamma"]), alpha=lambda ep: float(d["alpha"]), epsilon=eps, Q_init=d["Q_init"])
+            assert np.array_equal(Qh, Q) and np.array_equal(info_h["TD_errors"], info["TD_errors"])  # host loop (callable alpha) agrees
+            assert all(np.array_equal(a[5], b[5]) for a, b in zip(info["memory"], info_h["memory"]))  # replayed behaviour distributions
 
 
 def test_td_host_loop_fallback_matches_device(gpu):

@@ -404,3 +404,45 @@ def test_row_packed_scan_matches_the_window_kernel_at_scale(gpu):
         assert torch.equal(a.state.cursor, b.state.cursor) and torch.equal(a.state.rng, b.state.rng)
         dbg = oa["dbg"].cpu().numpy()
         assert (dbg[:, 0] + dbg[:, 1]).sum() < 0.05 * oa["steps"].sum().item()  # exact-path events stay rare
+
+
+# ---------------------------------------------------------------------------------------------------
+# f4: the batched evaluator for learners that reveal a distribution per step (thousands of environments per launch)
+# ---------------------------------------------------------------------------------------------------
+def test_vector_psrs_every_environment_is_the_reference_evaluator(gpu):
+    """VectorPSRS.step_dist_batch against the rows the reference's PerStateRejectionSampling served for the same sampler seed
+    (tests/golden/cartpole_2k.npz), five environments with seeds 0, 1, 0, 1, 7 stepped together, each reset on `done`."""
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces, synth
+    from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+    from rl_offline_simulation_amd.evaluators import VectorPSRS
+    d = load("cartpole_2k")
+    e = synth.cartpole_log(2000, seed=3)
+    ds = OfflineDataset(
+        observation_space=spaces.Box(low=-np.inf, high=np.inf, shape=(4,), dtype=np.float32), action_space=spaces.Discrete(2),
+        action_dist_type=ProbDistribution.Discrete, observations=e["observations"], actions=e["actions"],
+        action_distributions=e["action_distributions"], rewards=e["rewards"], next_observations=e["next_observations"],
+        terminals=e["terminals"], steps=e["steps"], episode_ids=e["episode_ids"])
+    seeds = [0, 1, 0, 1, 7]
+    env = VectorPSRS(ds, num_envs=len(seeds), num_states=162, encoder=CartpoleBoxEncoder())
+    env.reset_sampler(seeds)
+    obs, alive = env.reset()
+    assert alive.all() and obs.shape == (5, 4)
+    p = torch.tensor(np.tile(d["p_new_step"], (5, 1)), device=gpu)
+    served = [[] for _ in seeds]
+    for _ in range(2500):
+        a, obs, r, done, alive_now = env.step_dist_batch(torch.distributions.Categorical(probs=p) if _ % 2 else p)
+        a, obs_h, r, done, al = (x.cpu().numpy() for x in (a, obs, r, done, alive_now))
+        for k in range(len(seeds)):
+            if al[k]:
+                served[k].append((int(a[k]), obs_h[k].copy(), float(r[k]), bool(done[k])))
+        if not al.any():
+            break
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).to(gpu))
+    for k, s in enumerate(seeds[:4]):
+        rows = d[f"s{s}_step_rows"]
+        rows = rows[rows >= 0]
+        assert len(served[k]) == len(rows), (k, len(served[k]), len(rows))
+        for (a, o, r, dn), row in zip(served[k], rows):
+            assert a == e["actions"][row] and np.array_equal(o, e["next_observations"][row]) and r == e["rewards"][row] and dn == bool(e["terminals"][row])
+    assert served[0] and len(served[4]) > 100
