@@ -12,7 +12,7 @@ every environment identical to the reference evaluator constructed from the same
     a, next_obs, r, done, alive = env.step_dist_batch(probs)   # probs [R, nA] (tensor or torch Distribution)
 
 Rows of environments that are exhausted (step_dist would return the all-None tuple) have alive == False and keep their
-previous observation.  Everything stays on the device; no per-environment Python work.
+previous observation.  Everything stays on the device; no per-environment Python work and (with strict=False) no host synchronisation per call.
 """
 import numpy as np
 import torch
@@ -30,7 +30,7 @@ except Exception:  # pragma: no cover
 
 
 class VectorPSRS:
-    def __init__(self, dataset, num_envs, num_states=None, encoder=None, device=None):
+    def __init__(self, dataset, num_envs, num_states=None, encoder=None, device=None, strict=False):
         # the validation of per_state_rejection.py:16-25
         if not is_discrete(dataset.observation_space) and num_states is None and encoder is None:
             raise ValueError("PerStateRejectionSampling only supports discrete observation spaces")
@@ -46,6 +46,7 @@ class VectorPSRS:
         n = len(zs)
         t0 = (np.asarray(e["steps"]) == 0) if "steps" in e else None
         self.num_envs = int(num_envs)
+        self.strict = bool(strict)  # raise KeyError like the reference (costs a host sync per call); otherwise such environments just stop
         self.table = TransitionTable(zs, e["actions"], e["rewards"], next_zs, e["terminals"],
                                      np.asarray(e["action_distributions"]).reshape(n, -1), t0, device=device)
         dev = self.table.device
@@ -69,7 +70,7 @@ class VectorPSRS:
         row = self.env.reset(mask).to(torch.int64)
         m = torch.ones_like(self.alive) if mask is None else mask.to(torch.bool)
         ok = m & (row >= 0)
-        self.obs[ok] = self._obs[row[ok]]
+        self.obs = torch.where(ok.reshape((-1,) + (1,) * (self.obs.dim() - 1)), self._obs[row.clamp(min=0)], self.obs)
         self.alive = torch.where(m, row >= 0, self.alive)
         return self.obs, self.alive
 
@@ -80,7 +81,7 @@ class VectorPSRS:
         if isinstance(action_dists, Distribution):
             action_dists = action_dists.probs
         row, status, _ = self.env.step(action_dists)
-        if bool((status == L.ST_KEYERROR).any()):
+        if self.strict and bool((status == L.ST_KEYERROR).any()):  # psrs.py:44: the state has no queue
             k = int(torch.nonzero(status == L.ST_KEYERROR)[0])
             raise KeyError(self.table.z_of(int(self.env.state.cur_slot[k])))
         ok = status == L.ST_OK
