@@ -446,3 +446,37 @@ def test_vector_psrs_every_environment_is_the_reference_evaluator(gpu):
         for (a, o, r, dn), row in zip(served[k], rows):
             assert a == e["actions"][row] and np.array_equal(o, e["next_observations"][row]) and r == e["rewards"][row] and dn == bool(e["terminals"][row])
     assert served[0] and len(served[4]) > 100
+
+
+@pytest.mark.parametrize("nS,R", [(200, 9), (256, 5), (12, 3)])
+def test_row_packed_scan_with_fewer_wavefronts_per_workgroup(nS, R, gpu):
+    """The workgroup of the row-packed scan holds as many chain wavefronts as the CU's LDS has room for rollout regions: four at
+    163 states, three at 200, two at 256.  Each shape against the oracle (accepted rows, candidates, per-episode returns)."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    N = 60_000
+    e = synth.synth_iid(N, nS, 3, seed=nS)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    assert table.n_slots == nS
+    pi = synth.dirichlet_policy(nS, 3)
+    seeds = list(range(40, 40 + R))
+    for trace in (False, True):
+        env = BatchedPSRS(table, R)
+        env.reset_sampler(seeds, policy=table.policy_slots(pi))
+        o = env.eval_mc(table.policy_slots(pi), 0.95, ep_cap=table.N0 + 1, trace_cap=N if trace else 0)
+        assert env.scan_variant() == "k_eval_mc_rows"
+        torch.cuda.synchronize()
+        ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+        for i, s in enumerate(seeds):
+            ora.reset_sampler(s)
+            ref = ora.evalmc(10 ** 9, pi, 0.95, trace_cap=N)
+            n = ref["steps"]
+            assert int(o["steps"][i]) == n and int(o["cand"][i]) == ref["candidates"]
+            ne = int(o["n_ep"][i])
+            assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+            assert np.array_equal(o["ep_len"][i, : int(o["n_len"][i])].cpu().numpy(), ref["lengths"])
+            if trace:
+                assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])
