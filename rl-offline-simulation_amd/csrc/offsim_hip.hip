@@ -963,6 +963,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_mc_keys: required output is NULL%s");
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: candidate windows support at most 256 states%s");
+    if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: queue positions, candidate and step counters are 32-bit (N < 2^32)%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_keys: gamma_pow is NULL%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -480,3 +480,45 @@ def test_row_packed_scan_with_fewer_wavefronts_per_workgroup(nS, R, gpu):
             assert np.array_equal(o["ep_len"][i, : int(o["n_len"][i])].cpu().numpy(), ref["lengths"])
             if trace:
                 assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])
+
+
+@pytest.mark.timeout(900)
+def test_headline_job_every_rollout_two_independent_kernels(gpu):
+    """The whole headline job -- 10 M transitions x 4096 rollouts, per-rollout shuffles -- through the two independent
+    implementations of the scan (row-packed scan with helper wavefronts on candidate streams; round 1's window kernel on
+    permutations): accepted steps, candidates, completed episodes, sums of returns (bit for bit), cursors and stream state of
+    all 4096 rollouts must agree.  Needs most of the GPU's memory (246 GB of streams, then 164 GB of permutations)."""
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 262 * 2 ** 30:
+        pytest.skip(f"needs 262 GiB of free device memory, {free / 2 ** 30:.0f} GiB available")
+    N, nS, nA, R = 10_000_000, 162, 2, 4096
+    e = synth.synth_iid(N, nS, nA, seed=20221107)
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi = table.policy_slots(synth.dirichlet_policy(nS, nA))
+    seeds = np.arange(R)
+    res = []
+    for rows in (True, False):
+        env = BatchedPSRS(table, R)
+        if rows:
+            env.reset_sampler(seeds, policy=pi)
+            assert env.scan_variant() == "k_eval_mc_rows"
+            o = env.eval_mc(pi, 0.99)
+        else:
+            env.reset_sampler(seeds)
+            os.environ["OFFSIM_SCAN_ROWS"] = "0"
+            try:
+                o = env.eval_mc(pi, 0.99)
+            finally:
+                del os.environ["OFFSIM_SCAN_ROWS"]
+        torch.cuda.synchronize()
+        res.append({k: o[k].clone() for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status")} |
+                   {"cursor": env.state.cursor.clone(), "rng": env.state.rng.clone(), "cur_slot": env.state.cur_slot.clone()})
+        del env, o
+        torch.cuda.empty_cache()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert int(res[0]["steps"].sum()) > 2.0e10
