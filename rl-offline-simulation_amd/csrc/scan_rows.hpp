@@ -41,6 +41,7 @@ namespace offsim {
 #define ROWS_W 8u
 #define ROWS_EMPTY 0u      // window slot without a candidate (a draw is never <= 0: ring entries carry a set low bit)
 #define ROWS_BIAS 0x8000u  // window entries are digest - 16 units of T21: "draw <= entry" is then a CLEAR accept
+#define ROWS_NOT_LANDED 0xffffffffu  // no digest has this value: the next-state field of a digest is < 0x3ff
 #define ROWS_AMB 0xffff7800u  // entry - draw >= this (i.e. the draw exceeds the entry by at most 17 units): the exact look decides
 // per-rollout LDS region (byte offsets); window rows are 32-byte aligned, the region a multiple of 512
 #define RO_RING 0u       // 256 draws, k21 << 11 | 1: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
@@ -568,8 +569,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 cp = LV32(sync_a + SY_C);
                 if (gen - cp < 240u) {
                     while (gen - cp < 240u) gen16();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring entries first, then the count
-                    LV32(sync_a + SY_GEN) = gen;
+                    LV32(sync_a + SY_GEN) = gen;  // (behind the ring entries: the LDS runs one wavefront's DS instructions in issue order)
                 }
                 if (__ballot(tk <= k) == 0ull) {
                     ok = true;
@@ -579,25 +579,28 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
             if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads of the previous tick
+            // The chain has read the RQ slots of the previous round (before it published this tick): mark them "not landed".
+            // The helper never waits for the digests it requests; the chain lands what has arrived (it has, a tick later).
+            LV32(dma_a + DS_RQ0 * 256u + lane * 4u) = ROWS_NOT_LANDED;
+            LV32(dma_a + DS_RQ1 * 256u + lane * 4u) = ROWS_NOT_LANDED;
+            LV32(dma_a + DS_RQ2 * 256u + lane * 4u) = ROWS_NOT_LANDED;
+            LV32(dma_a + DS_RQ3 * 256u + lane * 4u) = ROWS_NOT_LANDED;
             const uint32_t la = rbase + ((k & 1u) ? RO_LOG2 : RO_LOG);
             const uint32_t n = LV32(sync_a + ((k & 1u) ? SY_N1 : SY_N0));
             const scan_u32x2 le = LV64(la + li * 8u);
             fin = LV32(sync_a + SY_FIN);
             cp = LV32(sync_a + SY_C);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned: the chain may reuse the buffer
-            LV32(sync_a + SY_HTICK) = k + 1u;
+            LV32(sync_a + SY_HTICK) = k + 1u;  // (behind the reads of the buffer: the chain may reuse it)
             {   // the window top-ups this tick's steps call for; the chain lands them at the end of its next tick
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
-                request(li < n, le.y & 0x3ffu, q_s, q_p, q_n);
+                request(li < n, le.y & 0x3ffu, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
                 LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
             }
-            rewards_a();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the requested digests (issued ~one R3 ago) and their descriptors are in LDS
             LV32(sync_a + SY_REQ) = k + 1u;
+            rewards_a();
             rewards_b(n, le, 0u);
             if (gen - cp < 240u) {
                 while (gen - cp < 240u) gen16();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 LV32(sync_a + SY_GEN) = gen;
             }
             if (__ballot(fin == 0u) == 0ull) break;  // every rollout of the wavefront has stopped: tick k was the last one
@@ -631,37 +634,65 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t n = dead ? nlog_dead : ROWS_TICK;
         nlog_dead = 0;
         n_tick++;
+        uint32_t in_d0 = 0, in_d1 = 0, in_d2 = 0, in_d3 = 0, v_ht = 0, v_gen = 0;
+        scan_u32x2 le;
+        le.x = 0;
+        le.y = 0;
+        uint32_t pop_i = 0;
         if (HELPER) {
-            // the helper has made the requests of the PREVIOUS tick's steps (while this tick ran); their digests are in the RQ slots
+            // One batch of reads: the flag of the helper's request round (it made the requests of the PREVIOUS tick's steps while
+            // this tick ran), the descriptors and digests of that round, and the two counters the next tick needs.  A flag that
+            // is not there yet is rare (the helper is a tick ahead); only then are the reads repeated behind a bounded wait.
+            const uint32_t v_req = LV32(sync_a + SY_REQ);
+            uint32_t dsc = dma_slot(DS_RQD);
+            in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+            v_ht = LV32(sync_a + SY_HTICK);
+            v_gen = LV32(sync_a + SY_GEN);
             if (tick_k >= 1u) {
                 const uint32_t want_r = tick_k;
-                if (!spin_until([&]() { return LV32(sync_a + SY_REQ) >= want_r; }) && !dead) {
-                    status = OFFSIM_ST_PROTOCOL;
-                    dead = 1u;
+                if (__ballot(v_req < want_r) != 0ull) {
+                    if (!spin_until([&]() { return LV32(sync_a + SY_REQ) >= want_r; }) && !dead) {
+                        status = OFFSIM_ST_PROTOCOL;
+                        dead = 1u;
+                    }
+                    dsc = dma_slot(DS_RQD);
+                    in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
                 }
-                const uint32_t dsc = dma_slot(DS_RQD);
                 rq_p = dsc & 0x1ffffu;
                 rq_s = (dsc >> 17) & 0x3ffu;
                 rq_n = dsc >> 27;
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
+            le = LV64(log_a + li * 8u);
+            if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
+            in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
         }
         PF_PH(0);
-        const scan_u32x2 le = LV64(log_a + li * 8u);
-        uint32_t pop_i = 0;
-        if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
-        const uint32_t in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
-        PF_PH(1);
         // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
-        // covered meanwhile is skipped, whatever does not fit is requested again later.
+        // covered meanwhile is skipped, whatever does not fit -- or has not arrived -- is requested again later.
+        uint32_t land_cs = 0, land_ld = 0;
         if (rq_n) {
-            const uint32_t cs = LV32(cons_a + rq_s * 4u);
-            uint32_t ld = LV32(land_a + rq_s * 4u);
+            land_cs = LV32(cons_a + rq_s * 4u);
+            land_ld = LV32(land_a + rq_s * 4u);
+        }
+        if (HELPER) {
+            // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
+            // order); ahead of the landing, whose reads are still in flight -- a request made from the older end of a window
+            // lands only as far as it still fits
+            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
+            LV32(sync_a + SY_C) = c;
+            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
+            LV32(sync_a + SY_TICK) = tick_k + 1u;
+        }
+        PF_PH(1);
+        if (rq_n) {
+            const uint32_t cs = land_cs;
+            uint32_t ld = land_ld;
             const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
 #pragma unroll
             for (uint32_t e = 0; e < 4u; e++) {
-                if (e < rq_n && rq_p + e == ld && ld - cs < ROWS_W) {
+                if (e < rq_n && dd[e] != ROWS_NOT_LANDED && rq_p + e == ld && ld - cs < ROWS_W) {
                     LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = rows_bias(dd[e]);
                     ld++;
                 }
@@ -671,12 +702,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
         PF_PH(2);
         if (HELPER) {
-            // hand the tick's log to the helper: data, then (behind a wait) the flag
-            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
-            LV32(sync_a + SY_C) = c;
-            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            LV32(sync_a + SY_TICK) = tick_k + 1u;
             steps += n;
             tick_k++;
             log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
@@ -684,12 +709,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 if (ic - ib >= 8u) load_init();
                 // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
                 const uint32_t want_h = tick_k - 1u;
-                if (!spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
+                if (__ballot(v_ht < want_h) != 0ull && !spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
                     status = OFFSIM_ST_PROTOCOL;
                     dead = 1u;
                 }
                 if (!dead) {
-                    gen = LV32(sync_a + SY_GEN);
+                    gen = v_gen;
                     need_draws(136u, 0u);
                 }
             }
@@ -733,124 +758,138 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
         uint32_t zz = z, logaddr = log_a + it * 8u - 8u;
-        uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn;
+        uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn, w2;
         uint64_t amb, ev;
         // One copy of the step; the loop body is four of them (the taken branch of the back edge is paid once per four steps).
-        // Ordering rule inside a copy: a VALU result is not consumed by the next instruction (a single wavefront pays ~2.6
-        // cycles for that), the three reads of the next look go out as early as their addresses exist -- ahead of this
-        // step's stores; if the next state is this state (vcc) they are repeated behind the stores, out of line -- and the
-        // scalar event test comes late enough that the vector compares feeding it have long retired.
-#define ROWS_STEP(FIX, EPI, BACK)                                                                                              \
-            "s_waitcnt lgkmcnt(3)\n\t"                                   /* this look's entry, cursor and draw (the last step's three stores may be out) */ \
-            "v_and_or_b32 %[key], %[w], %[s7ff], %[lif]\n\t"             /* (lane + 1) << 28 | done << 10 | z_next */ \
-            "v_sub_co_u32 %[d], vcc, %[w], %[kt]\n\t"                    /* borrow: not a clear accept */ \
-            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"                                                                     \
+        // The step's time is the time from the arrival of the look's entry and draw to the ISSUE of the next look's two reads,
+        // plus the LDS latency: everything that is not needed for those two addresses (the 16-lane minimum over the keys, then
+        // one shift for the entry and shift + add + mask for the draw) is placed behind them, in the shadow of that latency.
+        // The next entry is read ahead of this step's stores -- if the next state is this state (vcc) it is read again behind
+        // them, out of line -- into the other of two registers (w / w2), since this step still needs its own; the cursor of
+        // the next state is read behind the stores and waited for only where it is used.  A VALU result is not consumed by the
+        // next instruction where that can be avoided, and a DPP operand is two instructions old.
+        // The state of a row (zz, vcons) is not copied at the end of a step either: odd copies take it from (zz, vcons) and
+        // leave the next one in (zn, vconsn), even copies the other way round; the exits put it where the C++ code expects it.
+#define ROWS_STEP(FIX, EPI, BACK, ZZ, VC, ZN, VCN, W, WN)                                                                     \
+            "s_waitcnt lgkmcnt(1)\n\t"                                   /* this look's entry and draw, the last step's stores (its cursor read may be out) */ \
+            "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */ \
+            "v_and_or_b32 %[key], " W ", %[s7ff], %[lif]\n\t"            /* (lane + 1) << 28 | done << 10 | z_next */ \
             "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"                                                               \
             "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
-            "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
+            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"                                                                     \
             "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_nop 1\n\t"                                                                                                 \
+            "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
+            "s_nop 0\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
             "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
-            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        /* 4 x candidates consumed by this step */     \
             "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
-            "v_and_b32 %[zn], %[s7ff], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
-            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
-            "v_cmp_le_u32_e64 %[ev], %[s400], %[zn]\n\t"                 /* episode end, or the all-ones key of a row without a clear accept */ \
-            "v_cndmask_b32_e64 %[d], %[w], 0, vcc\n\t"                                                                    \
-            "ds_read_b32 %[w], %[nrd]\n\t"                               /* next look's entry */                         \
-            "v_cmp_eq_u32_e64 vcc, %[zn], %[zz]\n\t"                     /* next state == this state: the reads are repeated behind the stores */ \
-            "v_lshl_add_u32 %[vconsn], %[zn], 2, %[consa]\n\t"                                                            \
-            "v_lshrrev_b32 %[cz1], 28, %[key]\n\t"                                                                        \
+            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        /* 4 x candidates consumed by this step */     \
+            "ds_read_b32 " WN ", %[nrd]\n\t"                             /* next look's entry */                         \
             "v_add_u32 %[c4], %[c4], %[k4]\n\t"                                                                           \
-            "v_add_u32 %[cz1], %[cz1], %[cz]\n\t"                         /* cursor behind the accepted candidate */     \
-            "ds_read_b32 %[cz], %[vconsn]\n\t"                           /* next state's cursor */                       \
+            "v_and_b32 " ZN ", %[s7ff], %[key]\n\t"                      /* next state (| done << 10: an event) */      \
             "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
-            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
+            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
             "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
+            "v_cndmask_b32_e64 %[d], " W ", 0, vcc\n\t"                                                                   \
+            "v_cmp_lt_u32_e64 %[ev], %[srmask], " ZN "\n\t"              /* episode end, or the all-ones key of a row without a clear accept (states are < 0x3fc) */ \
+            "v_lshrrev_b32 %[cz1], 28, %[key]\n\t"                                                                        \
+            "v_cmp_eq_u32_e64 vcc, " ZN ", " ZZ "\n\t"                   /* next state == this state: its entry is read again behind the stores */ \
+            "v_lshl_add_u32 " VCN ", " ZN ", 2, %[consa]\n\t"                                                             \
+            "s_waitcnt lgkmcnt(2)\n\t"                                   /* this state's cursor */                       \
+            "v_add_u32 %[cz1], %[cz1], %[cz]\n\t"                        /* cursor behind the accepted candidate */     \
+            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
             "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
             "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
             /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
-            "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                           \
-            "ds_write2_b32 %[logaddr], %[cz1], %[zz] offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
+            "ds_write_b32 " VC ", %[cz1]\n\t"                                                                             \
+            "ds_write2_b32 %[logaddr], %[cz1], " ZZ " offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                \
+            "ds_read_b32 %[cz], " VCN "\n\t"                             /* next state's cursor (behind the stores: right also if it is this state) */ \
             "s_cmp_lg_u64 vcc, 0\n\t"                                                                                     \
-            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
-            "v_lshl_add_u32 %[vrow], %[zn], 5, %[wina]\n\t"                                                               \
-            "v_mov_b32 %[vcons], %[vconsn]\n\t"                                                                           \
+            "v_lshl_add_u32 %[vrow], " ZN ", 5, %[wina]\n\t"                                                              \
             "s_cbranch_scc1 " FIX "f\n\t"                                                                                 \
             BACK ":\n\t"
         /* Out of line: the only event of the look is the end of an episode in some rows (psrs.py:249-269: env.reset() pops */   \
         /* the shuffled init queue).  The row's next initial states wait in its LDS ring; SY_LEFT says how many the loop may */  \
         /* take before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed with */ \
         /* the log word marked "done", the next state of those rows is their next initial state. */                           \
-#define ROWS_EPI(EPI, BACK)                                                                                               \
+#define ROWS_EPI(EPI, BACK, OUT, ZZ, VC, ZN, VCN, W, WN)                                                                  \
             EPI ":\n\t"                                                                                                    \
             "s_cmp_lg_u64 %[amb], 0\n\t"                                                                                   \
-            "s_cbranch_scc1 2f\n\t"                                     /* a lane needs the exact look */                  \
-            "v_cmp_le_u32_e32 vcc, 0x500, %[zn]\n\t"                    /* all-ones key: a row without a clear accept */   \
-            "s_cbranch_vccnz 2f\n\t"                                                                                       \
-            "v_cmp_le_u32_e32 vcc, 0x400, %[zn]\n\t"                    /* vcc: the rows whose episode ends */             \
-            "ds_read_b32 %[w], %[rsync] offset:36\n\t"                  /* (w and cz are free: their early reads are repeated below) */ \
+            "s_cbranch_scc1 " OUT "f\n\t"                               /* a lane needs the exact look */                  \
+            "v_cmp_le_u32_e32 vcc, 0x500, " ZN "\n\t"                   /* all-ones key: a row without a clear accept */   \
+            "s_cbranch_vccnz " OUT "f\n\t"                                                                                 \
+            "v_cmp_le_u32_e32 vcc, 0x400, " ZN "\n\t"                   /* vcc: the rows whose episode ends */             \
+            "ds_read_b32 " W ", %[rsync] offset:36\n\t"                 /* (this look's entry register and cz are free) */ \
             "ds_read_b32 %[cz], %[rsync] offset:32\n\t"                                                                    \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-            "v_cmp_eq_u32_e64 %[ev], 0, %[w]\n\t"                                                                          \
+            "v_cmp_eq_u32_e64 %[ev], 0, " W "\n\t"                                                                         \
             "s_and_b64 %[ev], %[ev], vcc\n\t"                                                                              \
-            "s_cbranch_scc1 2f\n\t"                                     /* a row may not take another reset here */       \
-            "ds_read_b32 %[vconsn], %[cz]\n\t"                          /* the next initial state */                      \
-            "v_subrev_u32 %[w], 1, %[w]\n\t"                                                                               \
+            "s_cbranch_scc1 " OUT "f\n\t"                               /* a row may not take another reset here */       \
+            "ds_read_b32 " VCN ", %[cz]\n\t"                            /* the next initial state */                      \
+            "v_subrev_u32 " W ", 1, " W "\n\t"                                                                             \
             "v_add_u32 %[cz], 4, %[cz]\n\t"                                                                                \
-            "v_or_b32 %[nrd], 0x400, %[zz]\n\t"                         /* log word of an episode end */                  \
+            "v_or_b32 %[nrd], 0x400, " ZZ "\n\t"                        /* log word of an episode end */                  \
             "s_mov_b64 exec, vcc\n\t"                                                                                      \
-            "ds_write_b32 %[rsync], %[w] offset:36\n\t"                                                                    \
+            "ds_write_b32 %[rsync], " W " offset:36\n\t"                                                                   \
             "ds_write_b32 %[rsync], %[cz] offset:32\n\t"                                                                   \
             "s_mov_b64 exec, -1\n\t"                                                                                       \
-            "v_cndmask_b32_e32 %[nrd], %[zz], %[nrd], vcc\n\t"                                                             \
+            "v_cndmask_b32_e32 %[nrd], " ZZ ", %[nrd], vcc\n\t"                                                            \
             "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
-            "v_cndmask_b32_e32 %[zn], %[zn], %[vconsn], vcc\n\t"                                                           \
-            "ds_write_b32 %[vcons], %[cz1]\n\t"                                                                            \
+            "v_cndmask_b32_e32 " ZN ", " ZN ", " VCN ", vcc\n\t"                                                           \
+            "ds_write_b32 " VC ", %[cz1]\n\t"                                                                              \
             "ds_write2_b32 %[logaddr], %[cz1], %[nrd] offset1:1\n\t"                                                       \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                 \
-            "v_lshl_add_u32 %[vcons], %[zn], 2, %[consa]\n\t"                                                              \
-            "v_lshl_add_u32 %[vrow], %[zn], 5, %[wina]\n\t"                                                                \
-            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                   \
+            "v_lshl_add_u32 " VCN ", " ZN ", 2, %[consa]\n\t"                                                              \
+            "v_lshl_add_u32 %[vrow], " ZN ", 5, %[wina]\n\t"                                                               \
+            "s_nop 0\n\t"                                                                                                  \
             "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                       \
-            "ds_read_b32 %[w], %[nrd]\n\t"                                                                                 \
-            "ds_read_b32 %[cz], %[vcons]\n\t"                                                                              \
+            "ds_read_b32 " WN ", %[nrd]\n\t"                                                                               \
+            "ds_read_b32 %[cz], " VCN "\n\t"                                                                               \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
             "s_branch " BACK "b\n\t"
-#define ROWS_FIX(FIX, BACK)                                                                                               \
-            FIX ":\n\t"                                                   /* some row stays in its state: entry and cursor again, behind the stores */ \
+#define ROWS_FIX(FIX, BACK, WN)                                                                                           \
+            FIX ":\n\t"                                                   /* some row stays in its state: its entry again, behind the stores */ \
             "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                      \
-            "ds_read_b32 %[w], %[nrd]\n\t"                                                                                \
-            "ds_read_b32 %[cz], %[vcons]\n\t"                                                                             \
+            "ds_read_b32 " WN ", %[nrd]\n\t"                                                                              \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
             "s_branch " BACK "b\n\t"
+#define RA "%[zz]", "%[vcons]", "%[zn]", "%[vconsn]", "%[w]", "%[w2]"
+#define RB "%[zn]", "%[vconsn]", "%[zz]", "%[vcons]", "%[w2]", "%[w]"
+#define ROWS_STEP_(...) ROWS_STEP(__VA_ARGS__)
+#define ROWS_EPI_(...) ROWS_EPI(__VA_ARGS__)
         asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"                                   // (the reads issue_reads() started)
             "1:\n\t"
-            ROWS_STEP("51", "71", "61")
+            ROWS_STEP_("51", "71", "61", RA)
             "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("52", "72", "62")
+            "s_cbranch_scc1 41f\n\t"
+            ROWS_STEP_("52", "72", "62", RB)
             "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("53", "73", "63")
+            "s_cbranch_scc1 3f\n\t"
+            ROWS_STEP_("53", "73", "63", RA)
             "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 4f\n\t"
-            ROWS_STEP("54", "74", "64")
+            "s_cbranch_scc1 41f\n\t"
+            ROWS_STEP_("54", "74", "64", RB)
             "s_cmp_lt_u32 %[it], 16\n\t"
             "s_cbranch_scc1 1b\n\t"
-            "4:\n\t"
             "s_branch 3f\n\t"
-            ROWS_FIX("51", "61")
-            ROWS_FIX("52", "62")
-            ROWS_FIX("53", "63")
-            ROWS_FIX("54", "64")
-            ROWS_EPI("71", "61")
-            ROWS_EPI("72", "62")
-            ROWS_EPI("73", "63")
-            ROWS_EPI("74", "64")
+            ROWS_FIX("51", "61", "%[w2]")
+            ROWS_FIX("52", "62", "%[w]")
+            ROWS_FIX("53", "63", "%[w2]")
+            ROWS_FIX("54", "64", "%[w]")
+            ROWS_EPI_("71", "61", "2", RA)
+            ROWS_EPI_("72", "62", "22", RB)
+            ROWS_EPI_("73", "63", "2", RA)
+            ROWS_EPI_("74", "64", "22", RB)
+            "41:\n\t"                                                    // the tick ended behind an odd copy
+            "v_mov_b32 %[zz], %[zn]\n\t"
+            "v_mov_b32 %[vcons], %[vconsn]\n\t"
+            "s_branch 3f\n\t"
+            "22:\n\t"                                                    // event in an even copy: its state is in (zn, vconsn)
+            "v_mov_b32 %[zz], %[zn]\n\t"
+            "v_mov_b32 %[vcons], %[vconsn]\n\t"
             "2:\n\t"
             "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
             "s_sub_u32 %[it], %[it], 1\n\t"
@@ -858,13 +897,17 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
             : [w] "+v"(w), [kt] "+v"(kt), [cz] "+v"(cz), [c4] "+v"(c4), [vrow] "+v"(vrow_w), [vcons] "+v"(vcons), [zz] "+v"(zz),
               [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
-              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
+              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [w2] "=&v"(w2), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
             : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a), [li4w] "v"(li4w),
-              [rsync] "v"(sync_a), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [s400] "s"(0x400u), [srmask] "s"(ROWS_RING * 4u - 4u)
+              [rsync] "v"(sync_a), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [srmask] "s"(ROWS_RING * 4u - 4u)
             : "vcc", "scc", "memory");
 #undef ROWS_STEP
 #undef ROWS_FIX
 #undef ROWS_EPI
+#undef ROWS_STEP_
+#undef ROWS_EPI_
+#undef RA
+#undef RB
         c = (c4 - li4w) >> 2;
         z = zz;
         {
