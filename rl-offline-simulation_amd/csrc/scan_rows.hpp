@@ -45,10 +45,10 @@ namespace offsim {
 #define ROWS_AMB 0xffff7800u  // entry - draw >= this (i.e. the draw exceeds the entry by at most 17 units): the exact look decides
 // per-rollout LDS region (byte offsets); window rows are 32-byte aligned, the region a multiple of 512
 #define RO_RING 0u       // 256 draws, k21 << 11 | 1: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
-#define RO_INIT 1024u    // 16 upcoming initial states (slot or -1)
-#define RO_LOG 1088u     // 16 x {cursor behind the accepted candidate, state left | done << 10}; reused as the prod scratch
-#define RO_POP 1216u     // 16 x candidates popped by the step (TRACE)
+#define RO_INIT 1024u    // ring of 32 upcoming initial states (slot or -1), entry k of the queue at (k - first) & 31
+#define RO_LOG 1152u     // 16 x {cursor behind the accepted candidate, state left | done << 10}
 #define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
+#define RO_POP RO_LOG2   // 16 x candidates popped by the step (TRACE, which is never a HELPER build)
 #define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
 enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24, SY_REQ = 28,  // byte offsets in RO_SYNC
        SY_INITP = 32, SY_LEFT = 36 };  // chain loop: LDS address of the row's next initial state, episode ends it may still serve itself
@@ -234,16 +234,36 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
     };
 
-    // ---- initial states: ring of the next 16 entries of the shuffled init queue (psrs.py:22-23, 32-37) ----
-    uint32_t ic = ro.init_cursor[rr], ib = ic, ep = 0;
-    auto load_init = [&]() {
-        ib = ic;
-        const uint32_t k = ic + li;
-        int v = -1;
-        if (k < N0) v = t.init_slot[init_row ? init_row[k] : k];
-        LV32(rbase + RO_INIT + li4) = (uint32_t)v;
+    // ---- initial states (psrs.py:22-23, 32-37): ring of 32 entries of the shuffled init queue, filled 16 at a time ----
+    // The two dependent loads behind an initial state (queue entry -> row -> slot) never stall a tick: the next 16 entries
+    // are fetched into registers one load per tick (pf_st 1: rows requested, 2: slots requested) and stored as soon as the
+    // half of the ring they go to has been consumed; a rollout that runs into the end of what is stored (16 episode ends
+    // within three ticks) finishes the fetch on the spot.
+    const uint32_t ic0 = ro.init_cursor[rr], init_a = rbase + RO_INIT;
+    uint32_t ic = ic0, filled = ic0, ep = 0, pf_st = 0;
+    int pf_v = -1;
+    auto prefetch_rows = [&]() {
+        const uint32_t k = filled + li;
+        pf_v = k < N0 ? (init_row ? (int)init_row[k] : (int)k) : -1;
+        pf_st = 1u;
     };
-    if (!is_helper) load_init();
+    auto prefetch_step = [&]() {
+        if (pf_st == 2u) {
+            if ((int32_t)(filled - ic) <= 16) {  // the half these 16 go to has been consumed
+                LV32(init_a + (((filled + li - ic0) & 31u) << 2)) = (uint32_t)pf_v;
+                filled += 16u;
+                prefetch_rows();
+            }
+        } else if (pf_st == 1u) {
+            pf_v = pf_v >= 0 ? t.init_slot[pf_v] : -1;
+            pf_st = 2u;
+        }
+    };
+    if (!is_helper) {
+        prefetch_rows();
+        prefetch_step();
+        prefetch_step();  // entries [ic0, ic0 + 16) are stored, the rows of the next 16 requested
+    }
 
     // ---- per-row state ----
     uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
@@ -273,11 +293,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             z = 0xffffffffu;
             return;
         }
-        if (ic - ib >= 16u) load_init();
-        z = LV32(rbase + RO_INIT + ((ic - ib) << 2));
+        while (ic >= filled) prefetch_step();  // (ic < N0: the fetch is never idle here; at most two rounds)
+        z = LV32(init_a + (((ic - ic0) & 31u) << 2));
         ic++;
     };
-    if (!dead) do_reset(0u);
+    if (!dead && !is_helper) do_reset(0u);
 
     // chain registers: w = this lane's window entry of the current state, kt = its draw, cz = the state's cursor
     uint32_t vrow_w = 0, vcons = 0, w = 0, kt = 0, cz = 0;
@@ -686,7 +706,23 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             LV32(sync_a + SY_TICK) = tick_k + 1u;
         }
         PF_PH(1);
-        if (rq_n) {
+        if (__ballot(rq_n != 0u && rq_p != land_ld) == 0ull) {
+            // every request of the wavefront starts at its window's end (no direct read in between, the usual case): the
+            // first k entries land, k = what was asked for, has arrived and fits; the other stores go to a scratch word
+            const uint32_t have = land_ld - land_cs;
+            uint32_t k = in_d0 == ROWS_NOT_LANDED ? 0u : in_d1 == ROWS_NOT_LANDED ? 1u : in_d2 == ROWS_NOT_LANDED ? 2u : in_d3 == ROWS_NOT_LANDED ? 3u : 4u;
+            k = k < rq_n ? k : rq_n;
+            const uint32_t room = have < ROWS_W ? ROWS_W - have : 0u;
+            k = k < room ? k : room;
+            const uint32_t dst = win_a + rq_s * 32u + (have << 2);
+            const uint32_t scratch = sync_a + 64u + li4;  // (the hand-off words end at 40)
+            LV32(k > 0u ? dst : scratch) = rows_bias(in_d0);
+            LV32(k > 1u ? dst + 4u : scratch) = rows_bias(in_d1);
+            LV32(k > 2u ? dst + 8u : scratch) = rows_bias(in_d2);
+            LV32(k > 3u ? dst + 12u : scratch) = rows_bias(in_d3);
+            if (rq_n) LV32(land_a + rq_s * 4u) = land_ld + k;
+            rq_n = 0;
+        } else if (rq_n) {
             const uint32_t cs = land_cs;
             uint32_t ld = land_ld;
             const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
@@ -706,7 +742,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             tick_k++;
             log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
             if (!dead) {
-                if (ic - ib >= 8u) load_init();
+                prefetch_step();
                 // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
                 const uint32_t want_h = tick_k - 1u;
                 if (__ballot(v_ht < want_h) != 0ull && !spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
@@ -724,7 +760,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             rewards_a();
             rewards_b(n, le, pop_i);
             if (!dead) {
-                if (ic - ib >= 8u) load_init();
+                prefetch_step();
                 while (gen - c < 240u) gen16();
             }
             PF_PH(7);
@@ -746,10 +782,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     uint64_t ex_amb = 0;
     auto fast_run = [&](uint32_t &it) {
         // episode ends the loop may serve itself: after this many the episode cap, the end of the init queue or the end of
-        // the 16-entry ring is reached and the C++ path has to look
-        const uint32_t initp0 = rbase + RO_INIT + ((ic - ib) << 2);
+        // what is stored in the ring is reached and the C++ path has to look
+        const uint32_t initp0 = init_a + (((ic - ic0) & 31u) << 2);
         {
-            uint32_t left = 16u - (ic - ib);
+            uint32_t left = filled - ic;
             left = left < N0 - ic ? left : N0 - ic;  // (ic <= N0)
             const uint32_t cap = ep + 1u < max_episodes ? max_episodes - ep - 1u : 0u;
             left = left < cap ? left : cap;
@@ -830,6 +866,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "ds_read_b32 " VCN ", %[cz]\n\t"                            /* the next initial state */                      \
             "v_subrev_u32 " W ", 1, " W "\n\t"                                                                             \
             "v_add_u32 %[cz], 4, %[cz]\n\t"                                                                                \
+            "v_and_b32 %[cz], 0xffffff7f, %[cz]\n\t"                   /* the ring of 32 is 128-byte aligned: wrap */    \
             "v_or_b32 %[nrd], 0x400, " ZZ "\n\t"                        /* log word of an episode end */                  \
             "s_mov_b64 exec, vcc\n\t"                                                                                      \
             "ds_write_b32 %[rsync], " W " offset:36\n\t"                                                                   \
@@ -911,7 +948,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         c = (c4 - li4w) >> 2;
         z = zz;
         {
-            const uint32_t served = (LV32(sync_a + SY_INITP) - initp0) >> 2;  // episode ends the loop served
+            const uint32_t served = ((LV32(sync_a + SY_INITP) - initp0) >> 2) & 31u;  // episode ends the loop served (the pointer wraps)
             ic += served;
             ep += served;
         }
