@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     };
 
 #ifdef OFFSIM_ROWS_PROF
-    uint64_t pf_fast = 0, pf_slow = 0, pf_tick = 0, pf_nslow = 0, pf_t0 = 0, pf_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t1 = 0;
+    uint64_t pf_fast = 0, pf_slow = 0, pf_tick = 0, pf_nslow = 0, pf_t0 = 0, pf_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t1 = 0;
 #define PF_START() pf_t0 = __builtin_amdgcn_s_memtime()
 #define PF_ADD(x) x += __builtin_amdgcn_s_memtime() - pf_t0
 #define PF_PH(k) { const uint64_t _n = __builtin_amdgcn_s_memtime(); pf_ph[k] += _n - pf_t1; pf_t1 = _n; }
@@ -580,6 +580,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LV32(sync_a + SY_GEN) = gen;  // the first 240 draws are in the ring
         uint32_t fin = 0;
+#ifdef OFFSIM_ROWS_PROF
+        pf_t1 = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t k = 0;; k++) {
             // wait for the chain to publish tick k; meanwhile keep the ring topped up (the chain may run short inside a tick)
             uint32_t cp = 0;
@@ -598,6 +601,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 __builtin_amdgcn_s_sleep(4);
             }
             if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
+            PF_PH(8);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads of the previous tick
             // The chain has read the RQ slots of the previous round (before it published this tick): mark them "not landed".
             // The helper never waits for the digests it requests; the chain lands what has arrived (it has, a tick later).
@@ -617,12 +621,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
+            PF_PH(9);
             rewards_a();
             rewards_b(n, le, 0u);
             if (gen - cp < 240u) {
                 while (gen - cp < 240u) gen16();
                 LV32(sync_a + SY_GEN) = gen;
             }
+            PF_PH(10);
             if (__ballot(fin == 0u) == 0ull) break;  // every rollout of the wavefront has stopped: tick k was the last one
         }
         scan_u32x2 none;
@@ -641,6 +647,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             out.sum_g[r] = sum_g;
             out.n_ep[r] = ep_acc;
             out.n_len[r] = n_len;
+#ifdef OFFSIM_ROWS_PROF
+            if (out.dbg && out.ep_g && out.ep_cap >= 24)
+                for (int k = 0; k < 12; k++) out.ep_g[r * out.ep_cap + 12 + k] = (double)pf_ph[k];
+#endif
         }
         return;
     }
@@ -1046,8 +1056,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 out.dbg[4 * r + 1] = (int64_t)pf_slow;
                 out.dbg[4 * r + 2] = (int64_t)pf_tick;
                 out.dbg[4 * r + 3] = (int64_t)(pf_nslow | ((uint64_t)n_dry << 32));
-                if (out.ep_g && out.ep_cap >= 8)
-                    for (int k = 0; k < 8; k++) out.ep_g[r * out.ep_cap + k] = (double)pf_ph[k];
+                if (out.ep_g && out.ep_cap >= 24)
+                    for (int k = 0; k < 12; k++) out.ep_g[r * out.ep_cap + k] = (double)pf_ph[k];
             }
 #else
             if (out.dbg) {

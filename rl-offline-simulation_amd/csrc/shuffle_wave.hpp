@@ -33,7 +33,8 @@ namespace offsim {
 #define SHUF_RG 2048u  // raw draws in the ring (power of two, multiple of 128)
 #define SHUF_SQ 1024u  // partners in the j ring (power of two, >= 3 * 128)
 #define SHUF_CAP16 65536u
-enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5 };  // words of the control block
+enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8 };  // words of the control block
+#define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
 
 // explicit LDS address space: keeps every ring / segment access a ds_* instruction (a generic pointer would make
 // them flat_* operations, which also tie up the vector-memory counter)
@@ -89,7 +90,45 @@ __global__ void __launch_bounds__(256)
     if (n <= n_lo || (LDS16 && n > n_hi)) return;  // this launch serves the chains with n_lo < n <= n_hi (its LDS is sized for n_hi)
     volatile uint32_t *x32 = (volatile uint32_t *)xg;
 
-    if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0;
+    // keyed form: the queue order goes out as {digest, 16-bit row} streams (offsim_shuffle_queues_keys)
+    const bool keyed = LDS16 && dig_out != nullptr && s < n_slots;
+    const uint32_t *dsrc = keyed ? dig32 + base_val : nullptr;
+    uint32_t *dg = keyed ? dig_out + (int64_t)r * N + base_val : nullptr;
+    uint16_t *lc = keyed ? loc_out + (int64_t)r * N + base_val : nullptr;
+    const uint32_t n_chunks = (n + SHUF_CH - 1u) / SHUF_CH;
+    // one chunk of the finished order, by one wavefront: positions [SHUF_CH * ch, SHUF_CH * (ch + 1)) -- the digest of the
+    // candidate at every queue position (gathered from this segment's slice of dig32: L2-resident, the same few hundred KB for
+    // every rollout's chain of this state) and its 16-bit row inside the segment
+    auto emit_chunk = [&](uint32_t ch) {
+        lds_vu32 *xw = (lds_vu32 *)x16;  // (volatile: read behind the progress word that says the chunk is final)
+        const uint32_t pairs = (n + 1u) >> 1, k0 = ch * (SHUF_CH / 2u) + (uint32_t)lane;
+        uint32_t two[4], d0[4], d1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t k = k0 + 64u * (uint32_t)u;
+            two[u] = k < pairs ? xw[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i1 = two[u] >> 16;  // (the slot behind an odd-length segment still holds its identity value n)
+            d0[u] = dsrc[two[u] & 0xffffu];
+            d1[u] = dsrc[i1 < n ? i1 : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t k = k0 + 64u * (uint32_t)u;
+            if (k < pairs) {
+                dg[2u * k] = d0[u];
+                lc[2u * k] = (uint16_t)(two[u] & 0xffffu);
+                if (2u * k + 1u < n) {
+                    dg[2u * k + 1u] = d1[u];
+                    lc[2u * k + 1u] = (uint16_t)(two[u] >> 16);
+                }
+            }
+        }
+    };
+
+    if (threadIdx.x < 16u) ctrl[threadIdx.x] = threadIdx.x == SH_ATOP ? n - 1u : (threadIdx.x == SH_EM0 || threadIdx.x == SH_EM1) ? n_chunks : 0u;
     if (threadIdx.x < 64u) win[threadIdx.x] = 0;
     if (LDS16) {  // identity, two entries per lane and store
         __attribute__((address_space(3))) uint32_t *xw = (__attribute__((address_space(3))) uint32_t *)x16;
@@ -113,6 +152,11 @@ __global__ void __launch_bounds__(256)
             const Jump j128 = pcg_jump(p.inc, 128);
             U128 st = pcg_apply(pcg_jump(p.inc, 64ull * g + (uint64_t)lane + 1), p.state);
             uint32_t blk = g, done_blocks = 0, cpub = 0;  // blk = index of the block this wavefront writes next
+            // Keyed form: a step of the chain never touches a position above its own, so the order is final from the top down
+            // while the chain still runs.  The two G wavefronts are ahead of C most of the time; while they wait for room in
+            // the draw ring they write the finished chunks out (even / odd chunks), one per poll; what is left when the chain
+            // ends goes out with the whole workgroup.
+            int32_t em_next = (int32_t)n_chunks - 1 - (int32_t)(((n_chunks - 1u) & 1u) != g);  // highest chunk of this parity
             for (;;) {
                 bool stop = false;
                 while ((blk + 1u) * 128u - cpub > SHUF_RG) {
@@ -120,7 +164,13 @@ __global__ void __launch_bounds__(256)
                         stop = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (keyed && em_next >= 0 && sh_ld(ctrl + SH_ATOP) < SHUF_CH * (uint32_t)em_next) {
+                        emit_chunk((uint32_t)em_next);
+                        sh_st(ctrl + (g ? SH_EM1 : SH_EM0), (uint32_t)em_next);  // this parity is out from here up
+                        em_next -= 2;
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                     cpub = sh_ld(ctrl + SH_CPUB);
                 }
                 if (stop) break;
@@ -288,6 +338,7 @@ __global__ void __launch_bounds__(256)
                 } else {
                     piecewise(64u, i_first, il, v, b, tg, confl, F);
                 }
+                if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);  // (behind the stores) positions above i_top are final
             }
             if (i_top >= 1u) {  // the last, partial group
                 const uint32_t cnt = i_top;
@@ -312,40 +363,11 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (LDS16) {  // the only HBM traffic of the chain: one coalesced write of the finished order
         __attribute__((address_space(3))) const uint32_t *xw = (__attribute__((address_space(3))) const uint32_t *)x16;
-        if (dig_out && s < n_slots) {
-            // keyed form (offsim_shuffle_queues_keys): the queue order as the scan wants to read it -- the digest of the
-            // candidate at every queue position (gathered from this segment's slice of dig32: L2-resident, the same few
-            // hundred KB for every rollout's chain of this state) and its 16-bit row inside the segment
-            const uint32_t *dsrc = dig32 + base_val;
-            uint32_t *dg = dig_out + (int64_t)r * N + base_val;
-            uint16_t *lc = loc_out + (int64_t)r * N + base_val;
-            const uint32_t pairs = (n + 1u) >> 1;
-            for (uint32_t k0 = threadIdx.x; k0 < pairs; k0 += 1024u) {  // four pairs per thread in flight
-                uint32_t two[4], d0[4], d1[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k = k0 + 256u * (uint32_t)u;
-                    two[u] = k < pairs ? xw[k] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i1 = two[u] >> 16;  // (the slot behind an odd-length segment still holds its identity value n)
-                    d0[u] = dsrc[two[u] & 0xffffu];
-                    d1[u] = dsrc[i1 < n ? i1 : 0u];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k = k0 + 256u * (uint32_t)u;
-                    if (k < pairs) {
-                        dg[2u * k] = d0[u];
-                        lc[2u * k] = (uint16_t)(two[u] & 0xffffu);
-                        if (2u * k + 1u < n) {
-                            dg[2u * k + 1u] = d1[u];
-                            lc[2u * k + 1u] = (uint16_t)(two[u] >> 16);
-                        }
-                    }
-                }
-            }
+        if (keyed) {
+            // the chunks the G wavefronts did not get to (the low end of the order)
+            const uint32_t em0 = ctrl[SH_EM0], em1 = ctrl[SH_EM1];
+            for (uint32_t ch = (uint32_t)wave; ch < n_chunks; ch += 4u)
+                if (ch < ((ch & 1u) ? em1 : em0)) emit_chunk(ch);
         } else {
             for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) {
                 const uint32_t two = xw[k];

@@ -12,7 +12,7 @@ pi = table.policy_slots(synth.dirichlet_policy(162, 2))
 env = BatchedPSRS(table, R)
 env.reset_sampler(list(range(R)), policy=pi)
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-t0.record(); o = env.eval_mc(pi, 0.99, dbg=True, ep_cap=8); t1.record(); torch.cuda.synchronize()
+t0.record(); o = env.eval_mc(pi, 0.99, dbg=True, ep_cap=24); t1.record(); torch.cuda.synchronize()
 d = o["dbg"].cpu().numpy()[::16]  # one lane-0 row per wavefront is enough (all rows of a wave stamp the same clock)
 steps = o["steps"].cpu().numpy().astype(float)
 it = steps.max()
@@ -22,5 +22,7 @@ print(f"kernel {t0.elapsed_time(t1):.1f} ms, iterations/wave ~{it:.0f}")
 print(f"memtime ticks per iteration: fast {fast / it:.1f} slow {slow / it:.1f} tick {tick / it:.1f}  (total {(fast + slow + tick) / it:.1f})")
 print(f"slow iterations {nslow / it * 100:.2f} % of all, {slow / max(nslow, 1):.0f} ticks each; tick() {tick / (it / 16):.0f} ticks each; dry events/row {ndry:.0f}")
 ph = o["ep_g"].cpu().numpy()[::16].mean(axis=0)
-names = ["vmcnt wait", "log+slot reads", "C land", "A request", "R3 sums", "R2 rewards", "R1 loc/discount", "init ring + draws"]
-print("tick phases (cycles per tick):", {n: int(v / (it / 16)) for n, v in zip(names, ph)})
+names = ["batch reads + flag", "land reads + hand-off", "landing", "-", "-", "-", "-", "counters, init prefetch, draws check"]
+print("chain tick phases (cycles per tick):", {n: int(v / (it / 16)) for n, v in zip(names, ph[:8]) if n != "-"})
+hn = {8: "poll (idle)", 9: "log read + requests", 3: "slot reads", 4: "R3 sums", 5: "R2 rewards", 6: "R1 loc/discount", 10: "draws"}
+print("helper phases (cycles per tick):", {v: int(ph[12 + k] / (it / 16)) for k, v in hn.items()})
