@@ -175,3 +175,46 @@ def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
                        ["-m", "gpu", "-x", "-q", "-k", "not every_scan_variant and not headline_table_size and not two_ranks"],
                        env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _compare_untraced(e, pi, gamma, seeds, gpu, t0=None, n_episodes=None):
+    """eval_mc without trace outputs (the helper-wavefront form of csrc/scan_rows.hpp wherever it applies) against the oracle:
+    counts, every episode's return and length, and the in-order sum of returns."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    t0 = (e["steps"] == 0) if t0 is None else t0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds)
+    o = env.eval_mc(table.policy_slots(pi), gamma, n_episodes=n_episodes, ep_cap=table.N0 + 1)
+    torch.cuda.synchronize()
+    import os
+    if os.environ.get("OFFSIM_SCAN_ROWS") != "0":
+        assert env.scan_variant() == "k_eval_mc_rows"  # (the candidate streams were derived: this ran the row-packed kernel)
+    ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    for i, s in enumerate(seeds):
+        ora.reset_sampler(s)
+        ref = ora.evalmc(10 ** 9 if n_episodes is None else n_episodes, pi, gamma)
+        assert int(o["steps"][i]) == ref["steps"] and int(o["cand"][i]) == ref["candidates"], (i, s)
+        ne = int(o["n_ep"][i])
+        assert ne == len(ref["Gs"])
+        assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+        assert np.array_equal(o["ep_len"][i, : int(o["n_len"][i])].cpu().numpy(), ref["lengths"])
+        acc = 0.0
+        for g in ref["Gs"]:
+            acc += float(g)
+        assert float(o["sum_g"][i]) == acc
+    return env, o
+
+
+@pytest.mark.parametrize("p_done,p_init,N", [(0.7, 0.8, 30000), (0.5, 0.5, 30000), (0.9, 0.02, 20000), (0.3, 0.0005, 20000), (0.02, 0.02, 3000)])
+def test_short_episodes_and_small_init_queues(p_done, p_init, N, gpu):
+    """Initial states reach the chain through a 32-entry LDS ring that is refilled one load per tick (csrc/scan_rows.hpp):
+    one- and two-step episodes use it up faster than it is refilled (the fetch is then finished on the spot), init queues
+    shorter than the ring or than one refill end the rollout with env.reset() returning None (psrs.py:33-35, 250-252)."""
+    from rl_offline_simulation_amd import synth
+    e = synth.synth_iid(N, 20, 3, seed=int(1000 * p_done) + N, p_done=p_done, p_init=p_init)
+    pi = synth.dirichlet_policy(20, 3)
+    _compare_untraced(e, pi, 0.9, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10], gpu)
+    _compare_untraced(e, pi, 0.9, [11, 12, 13], gpu, n_episodes=37)

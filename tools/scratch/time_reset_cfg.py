@@ -1,0 +1,16 @@
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from rl_offline_simulation_amd import synth
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+# usage: N nS R  -- iid synthetic log, few states -> big segments
+N, nS, R = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+e = synth.synth_iid(N, nS, 2, seed=1)
+t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+env = BatchedPSRS(t, R)
+seeds = np.arange(R, dtype=np.uint64)
+for k in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    env.reset_sampler(seeds)
+    torch.cuda.synchronize(); dt = time.time() - t0
+print(f"N={N} nS={nS} R={R}: reset_sampler {dt:.4f} s  ({N*R/dt:.3e} swaps/s)", flush=True)
