@@ -329,7 +329,10 @@ def test_sparse_state_ids_and_action_range(gpu):
 # ---------------------------------------------------------------------------------------------------
 # a2 in its keyed form: the sampler reset writes candidate streams instead of permutations
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,nS,skew", [(64, 1, False), (1001, 7, False), (50_000, 7, True), (120_000, 2, False), (200_000, 162, False)])
+@pytest.mark.parametrize("N,nS,skew", [(64, 1, False), (1001, 7, False), (50_000, 7, True), (120_000, 2, False), (200_000, 162, False),
+                                       # the keyed order leaves in 512-entry chunks while the chain still runs: lengths around the chunk size
+                                       (511, 1, False), (512, 1, False), (513, 1, False), (1023, 1, False), (1024, 1, False), (1537, 1, False),
+                                       (65_536, 1, False)])
 def test_keyed_reset_sampler_streams_equal_the_permutations(N, nS, skew, gpu):
     """offsim_shuffle_queues_keys (reset_sampler(policy=...)) must describe exactly the queue orders of offsim_shuffle_queues:
     loc[r][p] = perm[r][p] - seg_off[state of p], dig[r][p] = digest of the compiled key of row perm[r][p]; init orders equal.
