@@ -144,6 +144,22 @@ int offsim_step_batch(const offsim_table *t, offsim_rollouts *ro, const void *p_
 /* Sets the current state of masked rollouts (used after a Python-side accept): cur_slot[r] = slot[r]. */
 int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream);
 
+/* Payload of a batched step / reset for many environments at once (the vectorised form of per_state_rejection.py:85-95: the
+ * reference returns action, next observation, reward, done of the served row -- `experience[...][row]`).  One launch:
+ *   status != NULL (after offsim_step_batch):  ok[k] = status[k] == OFFSIM_ST_OK;  alive[k] &= ok[k]
+ *   status == NULL (after offsim_env_reset):   m = mask ? mask[k] : 1;  ok[k] = m && row[k] >= 0;  if (m) alive[k] = row[k] >= 0
+ * and for every column c < n_cols: where ok[k], dst_c[k] = src_c[row[k]] (row_bytes bytes); where not, dst_c[k] is left as it
+ * is, or zero-filled if zero_if_not_ok (e.g. `done`).  row are rows of the caller's buffer.  n_cols <= 8. */
+typedef struct {
+    const void *src; /* [n_rows] items of row_bytes bytes, caller's row order */
+    void *dst;       /* [R] items */
+    int64_t row_bytes;
+    int32_t zero_if_not_ok;
+    int32_t reserved;
+} offsim_column;
+int offsim_vector_gather(const int32_t *row, const int32_t *status, const uint8_t *mask, int32_t R, const offsim_column *cols,
+                         int32_t n_cols, uint8_t *alive, void *stream);
+
 /* evalMC_psrs(env, n_episodes, pi, gamma) (psrs.py:241-271) for all rollouts in one launch.
  * pi [n_slots,nA] (row s = policy in state slot s), same dtype rule as p_new.
  * gamma_pow [n_gamma_pow] f64 holds gamma**t as the host computes it (Python float ** int == libm pow); Gs are bit-exact

@@ -43,6 +43,11 @@ class Streams(C.Structure):
     _fields_ = [("dig", _vp), ("dig_stride", _i64), ("loc", _vp), ("loc_stride", _i64)]
 
 
+class Column(C.Structure):
+    """struct offsim_column"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("row_bytes", _i64), ("zero_if_not_ok", _i32), ("reserved", _i32)]
+
+
 class TD(C.Structure):
     """struct offsim_td"""
     _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64), ("behaviour", _i32), ("epsilon", C.c_double)]
@@ -63,6 +68,7 @@ SIGNATURES = {
     "offsim_shuffle_queues": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp, _vp]),
     "offsim_env_reset": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _vp, _vp]),
     "offsim_env_set_state": (C.c_int, [C.POINTER(Rollouts), _vp, _vp, _vp]),
+    "offsim_vector_gather": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
     "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), _vp]),

@@ -342,6 +342,56 @@ __global__ void k_env_set_state(offsim_rollouts ro, const int32_t *__restrict__ 
     if (mask && !mask[r]) return;
     ro.cur_slot[r] = slot[r];
 }
+// payload of a batched step / reset (offsim.h: offsim_vector_gather): one thread per environment
+struct VecCols {
+    offsim_column c[8];
+};
+__global__ void k_vector_gather(const int32_t *__restrict__ row, const int32_t *__restrict__ status, const uint8_t *__restrict__ mask, int32_t R,
+                                VecCols cols, int32_t n_cols, uint8_t *__restrict__ alive) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    const int32_t rw = row[k];
+    bool ok;
+    if (status) {
+        ok = status[k] == OFFSIM_ST_OK && rw >= 0;
+        if (alive) alive[k] = (uint8_t)(alive[k] && ok);
+    } else {
+        const bool m = mask ? mask[k] != 0 : true;
+        ok = m && rw >= 0;
+        if (alive && m) alive[k] = (uint8_t)(rw >= 0);
+    }
+    for (int c = 0; c < n_cols; c++) {
+        const int64_t nb = cols.c[c].row_bytes;
+        unsigned char *d = (unsigned char *)cols.c[c].dst + (int64_t)k * nb;
+        if (ok) {
+            const unsigned char *sp = (const unsigned char *)cols.c[c].src + (int64_t)rw * nb;
+            if (((nb | (int64_t)(uintptr_t)sp | (int64_t)(uintptr_t)d) & 3) == 0) {
+                for (int64_t b = 0; b < nb; b += 4) *(uint32_t *)(d + b) = *(const uint32_t *)(sp + b);
+            } else {
+                for (int64_t b = 0; b < nb; b++) d[b] = sp[b];
+            }
+        } else if (cols.c[c].zero_if_not_ok) {
+            for (int64_t b = 0; b < nb; b++) d[b] = 0;
+        }
+    }
+}
+
+extern "C" int offsim_vector_gather(const int32_t *row, const int32_t *status, const uint8_t *mask, int32_t R, const offsim_column *cols,
+                                    int32_t n_cols, uint8_t *alive, void *stream) {
+    if (!row || R < 0 || n_cols < 0 || n_cols > 8 || (n_cols > 0 && !cols)) return fail(OFFSIM_EINVAL, "vector_gather: bad argument%s");
+    VecCols vc;
+    memset(&vc, 0, sizeof(vc));
+    for (int c = 0; c < n_cols; c++) {
+        if (!cols[c].src || !cols[c].dst || cols[c].row_bytes <= 0) return fail(OFFSIM_EINVAL, "vector_gather: bad column%s");
+        vc.c[c] = cols[c];
+    }
+    if (R == 0) return OFFSIM_OK;
+    hipLaunchKernelGGL(k_vector_gather, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row, status, mask, R, vc, n_cols,
+                       alive);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 extern "C" int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream) {
     if (!ro || !slot || ro->R < 0) return fail(OFFSIM_EINVAL, "env_set_state: bad argument%s");
     if (ro->R == 0) return OFFSIM_OK;

@@ -12,7 +12,10 @@ every environment identical to the reference evaluator constructed from the same
     a, next_obs, r, done, alive = env.step_dist_batch(probs)   # probs [R, nA] (tensor or torch Distribution)
 
 Rows of environments that are exhausted (step_dist would return the all-None tuple) have alive == False and keep their
-previous observation.  Everything stays on the device; no per-environment Python work and (with strict=False) no host synchronisation per call.
+previous observation.  Everything stays on the device; no per-environment Python work and (with strict=False) no host
+synchronisation per call.  `obs` and `alive` are updated in place, and a call is nothing but kernel launches on the current
+stream, so a whole driver iteration (policy forward -> step_dist_batch -> reset of the finished environments) can be
+captured once in a HIP graph and replayed (`torch.cuda.graph`, see `graph_iteration`): the loop is launch-bound otherwise.
 """
 import numpy as np
 import torch
@@ -60,6 +63,22 @@ class VectorPSRS:
         self.observation_space, self.action_space = dataset.observation_space, dataset.action_space
         self.obs = torch.zeros((self.num_envs,) + tuple(self._obs.shape[1:]), dtype=self._obs.dtype, device=dev)
         self.alive = torch.zeros(self.num_envs, dtype=torch.bool, device=dev)
+        # outputs of step_dist_batch (overwritten by every call) and the column descriptors of offsim_vector_gather
+        self._obs, self._next_obs, self._a, self._r, self._done = (x.contiguous() for x in (self._obs, self._next_obs, self._a, self._r, self._done))
+        self.action = torch.zeros(self.num_envs, dtype=self._a.dtype, device=dev)
+        self.reward = torch.zeros(self.num_envs, dtype=self._r.dtype, device=dev)
+        self.done = torch.zeros(self.num_envs, dtype=torch.bool, device=dev)
+
+        def cols(*pairs):
+            arr = (L.Column * len(pairs))()
+            for c, (src, dst, zero) in zip(arr, pairs):
+                nb = src.element_size() * int(np.prod(src.shape[1:], dtype=np.int64))
+                assert nb == dst.element_size() * int(np.prod(dst.shape[1:], dtype=np.int64))
+                c.src, c.dst, c.row_bytes, c.zero_if_not_ok = src.data_ptr(), dst.data_ptr(), nb, int(zero)
+            return arr
+
+        self._cols_step = cols((self._next_obs, self.obs, False), (self._a, self.action, False), (self._r, self.reward, False), (self._done, self.done, True))
+        self._cols_reset = cols((self._obs, self.obs, False))
 
     def reset_sampler(self, seeds):
         self.env.reset_sampler(seeds)
@@ -67,25 +86,47 @@ class VectorPSRS:
 
     def reset(self, mask=None):
         """PSRS.reset (psrs.py:32-37) for the environments in `mask` (all if None).  Returns (obs [R, ...], alive [R])."""
-        row = self.env.reset(mask).to(torch.int64)
-        m = torch.ones_like(self.alive) if mask is None else mask.to(torch.bool)
-        ok = m & (row >= 0)
-        self.obs = torch.where(ok.reshape((-1,) + (1,) * (self.obs.dim() - 1)), self._obs[row.clamp(min=0)], self.obs)
-        self.alive = torch.where(m, row >= 0, self.alive)
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        row = self.env.reset(m)
+        L.check(L.load().offsim_vector_gather(L.ptr(row), None, L.ptr(m), self.num_envs, self._cols_reset, len(self._cols_reset),
+                                              L.ptr(self.alive), L.stream_ptr()))
         return self.obs, self.alive
 
     def step_dist_batch(self, action_dists):
         """per_state_rejection.py:85-95 for every environment at once.  action_dists: [R, nA] probabilities (tensor / array /
-        torch Distribution with .probs).  Returns device tensors (action, next_obs, reward, done, alive); entries of
-        environments with alive == False are meaningless (the reference returns the all-None tuple there)."""
+        torch Distribution with .probs).  Returns device tensors (action, next_obs, reward, done, alive) -- the environment's own
+        buffers, overwritten by the next call (clone what has to outlive it); entries of environments with alive == False are
+        meaningless (the reference returns the all-None tuple there; action / reward keep their last value, done is False)."""
         if isinstance(action_dists, Distribution):
             action_dists = action_dists.probs
         row, status, _ = self.env.step(action_dists)
         if self.strict and bool((status == L.ST_KEYERROR).any()):  # psrs.py:44: the state has no queue
             k = int(torch.nonzero(status == L.ST_KEYERROR)[0])
             raise KeyError(self.table.z_of(int(self.env.state.cur_slot[k])))
-        ok = status == L.ST_OK
-        rr = row.to(torch.int64).clamp_(min=0)
-        self.obs = torch.where(ok.reshape((-1,) + (1,) * (self.obs.dim() - 1)), self._next_obs[rr], self.obs)
-        self.alive = self.alive & ok
-        return self._a[rr], self.obs, self._r[rr], self._done[rr] & ok, self.alive
+        L.check(L.load().offsim_vector_gather(L.ptr(row), L.ptr(status), None, self.num_envs, self._cols_step, len(self._cols_step),
+                                              L.ptr(self.alive), L.stream_ptr()))
+        return self.action, self.obs, self.reward, self.done, self.alive
+
+    def graph_iteration(self, dist_fn, warmup=3):
+        """Capture one driver iteration in a HIP graph: probs = dist_fn(self.obs); step_dist_batch(probs); reset(mask=done).
+        Returns (graph, (action, reward, done)): every graph.replay() advances all environments by one step and leaves the
+        step's outputs in those three tensors (and in self.obs / self.alive).  `warmup` eager iterations run first on a side
+        stream (PyTorch's capture recipe; they are real steps of the environments).  strict must be False."""
+        if self.strict:
+            raise ValueError("graph capture needs strict=False (the KeyError check synchronises with the host)")
+
+        def iteration():
+            a, _, r, done, _ = self.step_dist_batch(dist_fn(self.obs))
+            self.reset(mask=done)
+            return a, r, done
+
+        side = torch.cuda.Stream(device=self.table.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            outs = iteration()
+        return g, outs

@@ -451,6 +451,47 @@ def test_vector_psrs_every_environment_is_the_reference_evaluator(gpu):
     assert served[0] and len(served[4]) > 100
 
 
+def test_vector_psrs_iteration_replayed_from_a_hip_graph_equals_the_eager_loop(gpu):
+    """VectorPSRS.graph_iteration: one driver iteration (policy forward, step_dist_batch, reset of the finished environments)
+    captured in a HIP graph and replayed must walk every environment through exactly the steps of the eager loop."""
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces, synth
+    from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+    from rl_offline_simulation_amd.evaluators import VectorPSRS
+    e = synth.cartpole_log(20000, seed=5)
+    ds = OfflineDataset(
+        observation_space=spaces.Box(low=-np.inf, high=np.inf, shape=(4,), dtype=np.float32), action_space=spaces.Discrete(2),
+        action_dist_type=ProbDistribution.Discrete, observations=e["observations"], actions=e["actions"],
+        action_distributions=e["action_distributions"], rewards=e["rewards"], next_observations=e["next_observations"],
+        terminals=e["terminals"], steps=e["steps"], episode_ids=e["episode_ids"])
+    R, warm, n_it = 33, 3, 60
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2)).to(gpu)
+    dist = lambda obs: torch.softmax(net(obs), dim=1).to(torch.float64)
+    envs = [VectorPSRS(ds, num_envs=R, num_states=162, encoder=CartpoleBoxEncoder()) for _ in range(2)]
+    for env in envs:
+        env.reset_sampler(np.arange(R))
+        env.reset()
+    eager, graphed = envs
+    g, (a_g, r_g, done_g) = graphed.graph_iteration(dist, warmup=warm)   # warm-up iterations and the capture pass are real steps?  no:
+    # (capture records, it does not execute) -> the graphed environments have taken `warm` steps so far
+    log_e, log_g = [], []
+    with torch.no_grad():
+        for _ in range(warm + n_it):
+            a, _, r, done, _ = eager.step_dist_batch(dist(eager.obs))
+            eager.reset(mask=done)
+            log_e.append((a.clone(), r.clone(), done.clone(), eager.obs.clone(), eager.alive.clone()))
+    for _ in range(n_it):
+        g.replay()
+        log_g.append((a_g.clone(), r_g.clone(), done_g.clone(), graphed.obs.clone(), graphed.alive.clone()))
+    torch.cuda.synchronize()
+    for k in range(n_it):
+        al = log_e[warm + k][4]
+        assert torch.equal(al, log_g[k][4])
+        for x, y in zip(log_e[warm + k][:4], log_g[k][:4]):
+            assert torch.equal(x[al], y[al]), k
+    assert torch.equal(eager.env.state.cursor, graphed.env.state.cursor) and torch.equal(eager.env.state.rng, graphed.env.state.rng)
+
+
 @pytest.mark.parametrize("nS,R", [(200, 9), (256, 5), (12, 3)])
 def test_row_packed_scan_with_fewer_wavefronts_per_workgroup(nS, R, gpu):
     """The workgroup of the row-packed scan holds as many chain wavefronts as the CU's LDS has room for rollout regions: four at
