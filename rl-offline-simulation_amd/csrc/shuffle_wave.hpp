@@ -31,7 +31,7 @@
 namespace offsim {
 
 #define SHUF_RG 2048u  // raw draws in the ring (power of two, multiple of 128)
-#define SHUF_SQ 1024u  // partners in the j ring (power of two, >= 3 * 128)
+#define SHUF_SQ 4096u  // partners in the j ring (power of two, >= 3 * 128): deep enough that C rarely waits behind a slow group of A
 #define SHUF_CAP16 65536u
 enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8 };  // words of the control block
 #define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
@@ -142,6 +142,19 @@ __global__ void __launch_bounds__(256)
     // instructions of a wavefront in issue order: data written before a counter is visible before the counter, and a
     // read issued after a counter was seen comes after the data.  So the counters are plain volatile words (the
     // volatile qualifier keeps the compiler from reordering them) and no s_waitcnt is spent on publishing.
+    // -DSHUF_PROF (tools/prof_shuffle.py): per role, clocks in its loop / waiting for its neighbour / in the named extra
+    // activity; written over the first 13 digests of the chain's stream, so the results of such a build are not usable
+#ifdef SHUF_PROF
+    uint64_t pf_wait = 0, pf_w0 = 0, pf_extra = 0;
+    const uint64_t pf_begin = __builtin_amdgcn_s_memtime();
+#define SPW0() pf_w0 = __builtin_amdgcn_s_memtime()
+#define SPW1() pf_wait += __builtin_amdgcn_s_memtime() - pf_w0
+#define SPX1() pf_extra += __builtin_amdgcn_s_memtime() - pf_w0
+#else
+#define SPW0()
+#define SPW1()
+#define SPX1()
+#endif
     if (n >= 2) {
         if (wave == 0 || wave == 3) {
             // ---------------- G (two wavefronts, alternate blocks of 128 draws): raw draws.  In block k lane l owns 64-bit
@@ -159,13 +172,20 @@ __global__ void __launch_bounds__(256)
             int32_t em_next = (int32_t)n_chunks - 1 - (int32_t)(((n_chunks - 1u) & 1u) != g);  // highest chunk of this parity
             for (;;) {
                 bool stop = false;
+                SPW0();
                 while ((blk + 1u) * 128u - cpub > SHUF_RG) {
                     if (sh_ld(ctrl + SH_DONE)) {
                         stop = true;
                         break;
                     }
                     if (keyed && em_next >= 0 && sh_ld(ctrl + SH_ATOP) < SHUF_CH * (uint32_t)em_next) {
+#ifdef SHUF_PROF
+                        const uint64_t e0 = __builtin_amdgcn_s_memtime();
                         emit_chunk((uint32_t)em_next);
+                        pf_extra += __builtin_amdgcn_s_memtime() - e0;  // G: writing chunks out (inside its waiting time)
+#else
+                        emit_chunk((uint32_t)em_next);
+#endif
                         sh_st(ctrl + (g ? SH_EM1 : SH_EM0), (uint32_t)em_next);  // this parity is out from here up
                         em_next -= 2;
                     } else {
@@ -173,6 +193,7 @@ __global__ void __launch_bounds__(256)
                     }
                     cpub = sh_ld(ctrl + SH_CPUB);
                 }
+                SPW1();
                 if (stop) break;
                 const uint64_t o = pcg_output(st);
                 st = pcg_apply(j128, st);
@@ -189,18 +210,24 @@ __global__ void __launch_bounds__(256)
             uint32_t mask = 0xffffffffu >> __builtin_clz(i);
             int lowpow = (int)((mask >> 1) + 1u);  // steps below this index use the next smaller mask
             auto wait_draws = [&](uint32_t upto) {
+                const bool waited = upto > avail;
+                if (waited) SPW0();
                 while (upto > avail) {
                     const uint64_t gg = *(lds_vu64 *)(ctrl + SH_GEN0);
                     const uint32_t g0 = sh_rfl((uint32_t)gg), g1 = sh_rfl((uint32_t)(gg >> 32));
                     avail = 128u * (g0 <= g1 ? 2u * g0 : 2u * g1 + 1u);  // contiguous blocks
                     if (upto > avail) __builtin_amdgcn_s_sleep(1);
                 }
+                if (waited) SPW1();
             };
             auto wait_room = [&](uint32_t upto) {  // the j ring may hold entries [tail, tail + SQ)
+                const bool waited = upto - tail > SHUF_SQ;
+                if (waited) SPW0();
                 while (upto - tail > SHUF_SQ) {
                     tail = sh_ld(ctrl + SH_TAIL);
                     if (upto - tail > SHUF_SQ) __builtin_amdgcn_s_sleep(1);
                 }
+                if (waited) SPX1();  // C: waiting for room in the j ring (A behind)
             };
             // strike optimistic accepts that do not hold, first one first, until all hold
             auto settle = [&](uint64_t &bal, int &rk, uint32_t v, uint32_t ib) {
@@ -316,9 +343,13 @@ __global__ void __launch_bounds__(256)
             // full groups: no lane masks anywhere on the common path.  (Fetching the next group's partners early was
             // measured slower: this wavefront is bound by the instructions it issues, not by the LDS round trips.)
             while (i_top >= 64u) {
-                while (fill - done < 64u) {
-                    fill = sh_ld(ctrl + SH_FILL);
-                    if (fill - done < 64u) __builtin_amdgcn_s_sleep(1);
+                if (fill - done < 64u) {
+                    SPW0();
+                    while (fill - done < 64u) {
+                        fill = sh_ld(ctrl + SH_FILL);
+                        if (fill - done < 64u) __builtin_amdgcn_s_sleep(1);
+                    }
+                    SPW1();
                 }
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 done += 64u;
@@ -336,7 +367,9 @@ __global__ void __launch_bounds__(256)
                     xwr(il, b);
                     xwr(v, a);
                 } else {
+                    SPW0();
                     piecewise(64u, i_first, il, v, b, tg, confl, F);
+                    SPX1();  // A: groups with a conflict
                 }
                 if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);  // (behind the stores) positions above i_top are final
             }
@@ -360,6 +393,9 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+#ifdef SHUF_PROF
+    const uint64_t pf_end = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
     if (LDS16) {  // the only HBM traffic of the chain: one coalesced write of the finished order
         __attribute__((address_space(3))) const uint32_t *xw = (__attribute__((address_space(3))) const uint32_t *)x16;
@@ -376,6 +412,15 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
+#ifdef SHUF_PROF
+    __syncthreads();
+    if (keyed && lane == 0 && n >= 64u) {  // units of 64 clocks
+        dg[3 * wave + 0] = (uint32_t)((pf_end - pf_begin) >> 6);
+        dg[3 * wave + 1] = (uint32_t)(pf_wait >> 6);
+        dg[3 * wave + 2] = (uint32_t)(pf_extra >> 6);
+        if (wave == 0) dg[12] = (uint32_t)((__builtin_amdgcn_s_memtime() - pf_begin) >> 6);
+    }
+#endif
 }
 
 }  // namespace offsim
