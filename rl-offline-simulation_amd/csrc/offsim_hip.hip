@@ -268,10 +268,11 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
     const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
     if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
-    HIP_TRY(allow_big_lds(k_shuffle_wave<true>, 160 * 1024));
+    HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG>), 160 * 1024));
+    HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_SMALL>), 160 * 1024));
     if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
-        hipLaunchKernelGGL(k_shuffle_wave<false>, dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(), st, t->seg_off, t->n_slots, t->N,
-                           t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
+        hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
+                           t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
         LAUNCH_CHECK();
     }
     // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
@@ -284,9 +285,14 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
         uint32_t need = 0;
         if (seg_in) need = max_seg < hi ? max_seg : hi;
         if (init_in && n0 > need) need = n0;
-        const size_t lds16 = shuf_fixed_lds_bytes() + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
-        hipLaunchKernelGGL(k_shuffle_wave<true>, dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0, seeds,
-                           n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
+        const uint32_t sq = k == 0 ? SHUF_SQ_BIG : SHUF_SQ_SMALL;
+        const size_t lds16 = shuf_fixed_lds_bytes(sq) + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
+        if (k == 0)
+            hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_BIG>), dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0,
+                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
+        else
+            hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0,
+                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
         LAUNCH_CHECK();
     }
     return OFFSIM_OK;

@@ -31,7 +31,11 @@
 namespace offsim {
 
 #define SHUF_RG 2048u  // raw draws in the ring (power of two, multiple of 128)
-#define SHUF_SQ 4096u  // partners in the j ring (power of two, >= 3 * 128): deep enough that C rarely waits behind a slow group of A
+// partners in the j ring (power of two, >= 3 * 128), a template parameter (as a kernel argument it cost 3.5 %): 4096 for the class of the longest LDS-resident
+// chains (deep enough that C rarely waits behind a slow group of A; there one chain fills a CU anyway), 1024 elsewhere (the
+// short chains of a skewed table share a CU, and their occupancy is what the fixed part of the LDS costs)
+#define SHUF_SQ_BIG 4096u
+#define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
 enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8 };  // words of the control block
 #define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
@@ -52,12 +56,12 @@ __device__ __forceinline__ int sh_rank(uint64_t m) {  // set bits of m in front 
 }
 
 // LDS layout: [ctrl 16 w][draw ring RG w][j ring SQ w + 64 w trash][64 w tag winners][segment]
-constexpr uint32_t shuf_fixed_lds_bytes() { return 4u * (16u + SHUF_RG + SHUF_SQ + 64u + 64u); }
+constexpr uint32_t shuf_fixed_lds_bytes(uint32_t sq) { return 4u * (16u + SHUF_RG + sq + 64u + 64u); }
 
 // LDS16 = true : segments of n_lo < n <= n_hi <= 65536 rows, kept in LDS as 16-bit local indices (one launch per size class,
 //                so that short chains are not held to the occupancy of the longest)
 // LDS16 = false: segments with n > n_lo rows, shuffled in place in global memory (32-bit)
-template <bool LDS16>
+template <bool LDS16, uint32_t SHUF_SQ>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
                    int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi,
