@@ -146,7 +146,7 @@ class OraclePSRS:
         return o
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().oracle_psrs_free(self._h)
             self._h = None
 

@@ -1,0 +1,88 @@
+"""Randomised parity sweep of the untraced fast path (sampler reset in its keyed or permutation form + the row-packed scan
+with helper wavefronts) against the CPU oracle: random table shapes, skews, episode / initial-state densities, rollout
+counts, discount factors and episode caps; every rollout's counts, per-episode returns and lengths must be equal.
+
+As a test: 150 cases (OFFSIM_FUZZ_CASES / OFFSIM_FUZZ_SEED override).  As a script, for longer sweeps on the GPU box:
+    python tests/test_gpu_fuzz.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def sweep(n_cases, seed, verbose=True):
+    import torch
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    g = np.random.default_rng(seed)
+    bad = 0
+    ran = rollouts = steps_checked = variants_rows = 0
+    t_start = time.time()
+    for case in range(n_cases):
+        nS = int(g.choice([1, 2, 3, 7, 25, 50, 162, 200, 256]))
+        nA = int(g.choice([2, 3, 5]))
+        N = int(g.choice([300, 3000, 20000, 60000, 150000]))
+        p_done = float(g.choice([0.002, 0.02, 0.1, 0.5, 0.9]))
+        p_init = float(g.choice([0.0005, 0.02, 0.2, 0.8]))
+        R = int(g.choice([1, 3, 4, 5, 16, 33]))
+        skew = bool(g.random() < 0.3)
+        cap = None if g.random() < 0.7 else int(g.integers(0, 40))
+        gamma = float(g.choice([0.0, 0.9, 0.99, 1.0]))
+        keyed = bool(g.random() < 0.6)
+        e = synth.synth_iid(N, nS, nA, seed=int(g.integers(1 << 30)), p_done=p_done, p_init=p_init)
+        if skew and nS > 1:
+            e["z"] = np.where(g.random(N) < 0.6, 0, e["z"]).astype(e["z"].dtype)
+        t0 = e["steps"] == 0
+        table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+        if table.max_seg > 65536:
+            continue
+        pi = synth.dirichlet_policy(nS, nA, seed=int(g.integers(1 << 30)))
+        seeds = [int(x) for x in g.integers(0, 1 << 40, R)]
+        env = BatchedPSRS(table, R)
+        env.reset_sampler(seeds, policy=table.policy_slots(pi) if keyed else None)
+        o = env.eval_mc(table.policy_slots(pi), gamma, n_episodes=cap, ep_cap=table.N0 + 1)
+        torch.cuda.synchronize()
+        variant = env.scan_variant()
+        ran += 1
+        variants_rows += variant == "k_eval_mc_rows"
+        ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+        desc = dict(case=case, nS=nS, nA=nA, N=N, p_done=p_done, p_init=p_init, R=R, skew=skew, cap=cap, gamma=gamma, keyed=keyed, variant=variant)
+        for i, sd in enumerate(seeds):
+            ora.reset_sampler(sd)
+            try:
+                ref = ora.evalmc(10 ** 9 if cap is None else cap, pi, gamma)
+            except KeyError:
+                if int(o["status"][i]) != 3:
+                    print("FAIL (KeyError expected)", desc, "rollout", i); bad += 1
+                continue
+            ne = int(o["n_ep"][i])
+            rollouts += 1
+            steps_checked += ref["steps"]
+            ok = (int(o["steps"][i]) == ref["steps"] and int(o["cand"][i]) == ref["candidates"] and ne == len(ref["Gs"])
+                  and np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+                  and np.array_equal(o["ep_len"][i, : int(o["n_len"][i])].cpu().numpy(), ref["lengths"]))
+            if not ok:
+                print("FAIL", desc, "rollout", i, "steps", int(o["steps"][i]), ref["steps"], "cand", int(o["cand"][i]), ref["candidates"], "n_ep", ne, len(ref["Gs"]))
+                bad += 1
+                break
+    summary = (f"{n_cases} cases drawn, {ran} run ({variants_rows} on the row-packed kernel), {rollouts} rollouts / {steps_checked} accepted steps compared, {bad} failures, {time.time() - t_start:.0f} s")
+    if verbose:
+        print(summary)
+    return bad, ran, steps_checked
+
+
+@pytest.mark.gpu
+def test_randomised_parity_sweep_of_the_untraced_fast_path():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    bad, ran, steps = sweep(int(os.environ.get("OFFSIM_FUZZ_CASES", "150")), int(os.environ.get("OFFSIM_FUZZ_SEED", "11")))
+    assert bad == 0 and ran > 100 and steps > 1_000_000
+
+
+if __name__ == "__main__":
+    b, _, _ = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 600, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    sys.exit(1 if b else 0)
