@@ -83,6 +83,34 @@ def test_randomised_parity_sweep_of_the_untraced_fast_path():
     assert bad == 0 and ran > 100 and steps > 1_000_000
 
 
+@pytest.mark.gpu
+def test_randomised_queue_lengths_shuffle_equals_numpy_generator_shuffle():
+    """Random queue lengths up to the LDS capacity (and a few beyond it, which take the global-memory variant), random seeds:
+    the orders written by both forms of the sampler reset equal default_rng(seed).shuffle (oracle restatement, psrs.py:29-30)."""
+    import torch
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    g = np.random.default_rng(int(os.environ.get("OFFSIM_FUZZ_SEED", "11")))
+    lengths = [int(x) for x in g.integers(1, 65537, 24)] + [int(x) for x in g.integers(1, 700, 12)] + [65535, 65536, 65537, 70001, 131073]
+    for n in lengths:
+        e = synth.synth_iid(n, 1, 2, seed=n)
+        table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+        seeds = [int(x) for x in g.integers(0, 1 << 62, 3)]
+        plain = BatchedPSRS(table, len(seeds))
+        plain.reset_sampler(seeds)
+        perm = (plain.state.perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        for k, sd in enumerate(seeds):
+            assert np.array_equal(perm[k, :n], O.permutation(sd, n)), (n, sd)
+        if n <= 65536:
+            keyed = BatchedPSRS(table, len(seeds))
+            keyed.reset_sampler(seeds, policy=table.policy_slots(synth.dirichlet_policy(1, 2)))
+            assert torch.equal(keyed.perm.to(torch.int64) & 0xFFFFFFFF, plain.state.perm.to(torch.int64) & 0xFFFFFFFF), n
+
+
 if __name__ == "__main__":
     b, _, _ = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 600, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     sys.exit(1 if b else 0)
