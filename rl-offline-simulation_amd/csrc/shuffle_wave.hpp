@@ -34,10 +34,11 @@ namespace offsim {
 // partners in the j ring (power of two, >= 3 * 128), a template parameter (as a kernel argument it cost 3.5 %): 4096 for the class of the longest LDS-resident
 // chains (deep enough that C rarely waits behind a slow group of A; there one chain fills a CU anyway), 1024 elsewhere (the
 // short chains of a skewed table share a CU, and their occupancy is what the fixed part of the LDS costs)
+#define SHUF_TAIL 4096u  // keyed chains of the longest class are cut here: steps below it run in a second launch (PHASE 2)
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
-enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8 };  // words of the control block
+enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8, SH_CSTOP = 9 };  // words of the control block
 #define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
 
 // explicit LDS address space: keeps every ring / segment access a ds_* instruction (a generic pointer would make
@@ -61,7 +62,14 @@ constexpr uint32_t shuf_fixed_lds_bytes(uint32_t sq) { return 4u * (16u + SHUF_R
 // LDS16 = true : segments of n_lo < n <= n_hi <= 65536 rows, kept in LDS as 16-bit local indices (one launch per size class,
 //                so that short chains are not held to the occupancy of the longest)
 // LDS16 = false: segments with n > n_lo rows, shuffled in place in global memory (32-bit)
-template <bool LDS16, uint32_t SHUF_SQ>
+// PHASE 0: the whole chain.  Keyed chains of the longest size class are cut in two launches instead: the last SHUF_TAIL
+// steps of a chain (i < 4096) are all conflicts and settles -- an eighth of the chain's time for a fifteenth of its steps,
+// with C done and only A working -- while the chain holds a whole CU's LDS.  PHASE 1 runs the steps n-1 .. SHUF_TAIL (the
+// cut is a mask boundary, where C's batches end exactly anyway), writes the order out (final above the cut, the 4096
+// positions below it as they stand) and leaves the number of 32-bit draws used in the first digest word of the chain;
+// PHASE 2 reloads those 4096 local rows (8 KB of LDS: several chains per CU), continues the random stream from that
+// count and finishes the low positions.
+template <bool LDS16, uint32_t SHUF_SQ, int PHASE = 0>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
                    int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi,
@@ -93,6 +101,11 @@ __global__ void __launch_bounds__(256)
     if (n == 0) return;
     if (n <= n_lo || (LDS16 && n > n_hi)) return;  // this launch serves the chains with n_lo < n <= n_hi (its LDS is sized for n_hi)
     volatile uint32_t *x32 = (volatile uint32_t *)xg;
+    static_assert(PHASE == 0 || LDS16, "the two-phase form is for LDS-resident keyed chains");
+    if (PHASE != 0 && (dig_out == nullptr || s >= n_slots)) return;
+    const uint32_t n_rows = n;                  // rows of the segment (local rows are < n_rows)
+    if (PHASE == 2) n = SHUF_TAIL;              // this launch sees the chain's low SHUF_TAIL positions only
+    const uint32_t stop_i = PHASE == 1 ? SHUF_TAIL : 1u;  // the chain runs while i >= stop_i
 
     // keyed form: the queue order goes out as {digest, 16-bit row} streams (offsim_shuffle_queues_keys)
     const bool keyed = LDS16 && dig_out != nullptr && s < n_slots;
@@ -116,7 +129,7 @@ __global__ void __launch_bounds__(256)
         for (int u = 0; u < 4; u++) {
             const uint32_t i1 = two[u] >> 16;  // (the slot behind an odd-length segment still holds its identity value n)
             d0[u] = dsrc[two[u] & 0xffffu];
-            d1[u] = dsrc[i1 < n ? i1 : 0u];
+            d1[u] = dsrc[i1 < n_rows ? i1 : 0u];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -134,7 +147,11 @@ __global__ void __launch_bounds__(256)
 
     if (threadIdx.x < 16u) ctrl[threadIdx.x] = threadIdx.x == SH_ATOP ? n - 1u : (threadIdx.x == SH_EM0 || threadIdx.x == SH_EM1) ? n_chunks : 0u;
     if (threadIdx.x < 64u) win[threadIdx.x] = 0;
-    if (LDS16) {  // identity, two entries per lane and store
+    uint32_t c_start = 0;  // PHASE 2: 32-bit draws the first phase used
+    if (PHASE == 2) {  // the low positions as the first phase left them, and its draw count
+        c_start = dg[0];
+        for (uint32_t k = threadIdx.x; k < SHUF_TAIL; k += 256u) x16[k] = lc[k];
+    } else if (LDS16) {  // identity, two entries per lane and store
         __attribute__((address_space(3))) uint32_t *xw = (__attribute__((address_space(3))) uint32_t *)x16;
         for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) xw[k] = ((2u * k + 1u) << 16) | (2u * k);
     } else {
@@ -167,7 +184,7 @@ __global__ void __launch_bounds__(256)
             const uint32_t g = wave == 0 ? 0u : 1u;
             const PcgInit p = pcg_seed(seeds[r]);
             const Jump j128 = pcg_jump(p.inc, 128);
-            U128 st = pcg_apply(pcg_jump(p.inc, 64ull * g + (uint64_t)lane + 1), p.state);
+            U128 st = pcg_apply(pcg_jump(p.inc, (uint64_t)(c_start >> 1) + 64ull * g + (uint64_t)lane + 1), p.state);
             uint32_t blk = g, done_blocks = 0, cpub = 0;  // blk = index of the block this wavefront writes next
             // Keyed form: a step of the chain never touches a position above its own, so the order is final from the top down
             // while the chain still runs.  The two G wavefronts are ahead of C most of the time; while they wait for room in
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(256)
         } else if (wave == 1) {
             // ---------------- C: the j sequence, 2 x 64 draws per iteration.  The second batch starts from i2 = i - accepts
             // of the first, so the wavefront has two independent instruction streams.
-            uint32_t i = n - 1u, c = 0, avail = 0, fill = 0, tail = 0, c_pub = 0;
+            uint32_t i = n - 1u, c = c_start & 1u, avail = 0, fill = 0, tail = 0, c_pub = 0;  // (an odd count: the high half of a 64-bit output is next)
             uint32_t mask = 0xffffffffu >> __builtin_clz(i);
             int lowpow = (int)((mask >> 1) + 1u);  // steps below this index use the next smaller mask
             auto wait_draws = [&](uint32_t upto) {
@@ -242,9 +259,9 @@ __global__ void __launch_bounds__(256)
                     f = bal & __ballot((int)v > (int)ib - rk);
                 }
             };
-            wait_draws(128u);
-            uint32_t r1 = ring[(uint32_t)lane], r2 = ring[64u + (uint32_t)lane];
-            while (i >= 1u) {
+            wait_draws(c + 128u);
+            uint32_t r1 = ring[c + (uint32_t)lane], r2 = ring[c + 64u + (uint32_t)lane];
+            while (i >= stop_i) {
                 wait_draws(c + 256u);  // this pair and the prefetch of the next
                 const uint32_t p1 = ring[(c + 128u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 const uint32_t p2 = ring[(c + 192u + (uint32_t)lane) & (SHUF_RG - 1u)];
@@ -304,6 +321,7 @@ __global__ void __launch_bounds__(256)
                     sh_st(ctrl + SH_CPUB, c);
                 }
             }
+            if (PHASE == 1) sh_st(ctrl + SH_CSTOP, c);  // (the cut is a mask boundary: i == SHUF_TAIL - 1 here, c counts from the stream's start)
             sh_st(ctrl + SH_DONE, 1u);
         } else {
             // ---------------- A: apply, 64 consecutive steps i_top, i_top - 1, ... per iteration (lane l: step i_top - l).
@@ -346,7 +364,8 @@ __global__ void __launch_bounds__(256)
             };
             // full groups: no lane masks anywhere on the common path.  (Fetching the next group's partners early was
             // measured slower: this wavefront is bound by the instructions it issues, not by the LDS round trips.)
-            while (i_top >= 64u) {
+            const uint32_t lo = stop_i - 1u;  // the chain's steps are i_top .. lo + 1
+            while (i_top >= 64u + lo) {
                 if (fill - done < 64u) {
                     SPW0();
                     while (fill - done < 64u) {
@@ -377,8 +396,8 @@ __global__ void __launch_bounds__(256)
                 }
                 if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);  // (behind the stores) positions above i_top are final
             }
-            if (i_top >= 1u) {  // the last, partial group
-                const uint32_t cnt = i_top;
+            if (i_top > lo) {  // the last, partial group
+                const uint32_t cnt = i_top - lo;
                 while (fill - done < cnt) {
                     fill = sh_ld(ctrl + SH_FILL);
                     if (fill - done < cnt) __builtin_amdgcn_s_sleep(1);
@@ -386,7 +405,7 @@ __global__ void __launch_bounds__(256)
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 const uint32_t il = i_top - (uint32_t)lane;
                 const bool in = (uint32_t)lane < cnt;
-                const uint64_t confl = __ballot(in && v < il && v >= 1u);
+                const uint64_t confl = __ballot(in && v < il && v > lo);
                 uint32_t b = 0, tg = (uint32_t)lane;
                 if (in) {
                     b = xrd(v);
@@ -415,6 +434,10 @@ __global__ void __launch_bounds__(256)
                 if (2u * k + 1u < n) xg[2u * k + 1u] = base_val + (two >> 16);
             }
         }
+    }
+    if (PHASE == 1) {  // (behind the write-out of chunk 0, which holds this word)
+        __syncthreads();
+        if (threadIdx.x == 0) dg[0] = ctrl[SH_CSTOP];
     }
 #ifdef SHUF_PROF
     __syncthreads();
