@@ -34,7 +34,7 @@ namespace offsim {
 // partners in the j ring (power of two, >= 3 * 128), a template parameter (as a kernel argument it cost 3.5 %): 4096 for the class of the longest LDS-resident
 // chains (deep enough that C rarely waits behind a slow group of A; there one chain fills a CU anyway), 1024 elsewhere (the
 // short chains of a skewed table share a CU, and their occupancy is what the fixed part of the LDS costs)
-#define SHUF_TAIL 4096u  // keyed chains of the longest class are cut here: steps below it run in a second launch (PHASE 2)
+#define SHUF_TAIL 8192u  // keyed chains of the longest class are cut here: steps below it run in a second launch (PHASE 2); measured 2048 / 4096 / 8192 / 16384: 0.604 / 0.580 / 0.559 / 0.563 s per pass
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
@@ -63,12 +63,12 @@ constexpr uint32_t shuf_fixed_lds_bytes(uint32_t sq) { return 4u * (16u + SHUF_R
 //                so that short chains are not held to the occupancy of the longest)
 // LDS16 = false: segments with n > n_lo rows, shuffled in place in global memory (32-bit)
 // PHASE 0: the whole chain.  Keyed chains of the longest size class are cut in two launches instead: the last SHUF_TAIL
-// steps of a chain (i < 4096) are all conflicts and settles -- an eighth of the chain's time for a fifteenth of its steps,
-// with C done and only A working -- while the chain holds a whole CU's LDS.  PHASE 1 runs the steps n-1 .. SHUF_TAIL (the
-// cut is a mask boundary, where C's batches end exactly anyway), writes the order out (final above the cut, the 4096
-// positions below it as they stand) and leaves the number of 32-bit draws used in the first digest word of the chain;
-// PHASE 2 reloads those 4096 local rows (8 KB of LDS: several chains per CU), continues the random stream from that
-// count and finishes the low positions.
+// steps of a chain are mostly conflicts and settles (the chance of a conflict in a group of 64 steps is ~6000 / i) and
+// cost far more than their share of the steps, while the chain holds a whole CU's LDS and its other roles have little left
+// to do.  PHASE 1 runs the steps n-1 .. SHUF_TAIL (the cut is a mask boundary, where C's batches end exactly anyway), writes
+// the order out (final above the cut, the SHUF_TAIL positions below it as they stand) and leaves the number of 32-bit
+// draws used in the first digest word of the chain; PHASE 2 reloads those local rows (16 KB of LDS: five chains per CU,
+// which hide each other's latencies), continues the random stream from that count and finishes the low positions.
 template <bool LDS16, uint32_t SHUF_SQ, int PHASE = 0>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
