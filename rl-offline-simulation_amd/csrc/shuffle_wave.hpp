@@ -34,7 +34,10 @@ namespace offsim {
 // partners in the j ring (power of two, >= 3 * 128), a template parameter (as a kernel argument it cost 3.5 %): 4096 for the class of the longest LDS-resident
 // chains (deep enough that C rarely waits behind a slow group of A; there one chain fills a CU anyway), 1024 elsewhere (the
 // short chains of a skewed table share a CU, and their occupancy is what the fixed part of the LDS costs)
-#define SHUF_TAIL 8192u  // keyed chains of the longest class are cut here: steps below it run in a second launch (PHASE 2); measured 2048 / 4096 / 8192 / 16384: 0.604 / 0.580 / 0.559 / 0.563 s per pass
+// cut of the keyed chains of the longest size class (see k_shuffle_wave).  Measured per pass of the headline job: uncut
+// 0.645 s; one cut at 2048 / 4096 / 8192 / 16384: 0.604 / 0.580 / 0.559 / 0.563 s; cuts at 32768 and 8192: 0.582 s; at
+// 8192 and 2048: 0.569 s
+#define SHUF_CUT 8192u
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
@@ -62,14 +65,17 @@ constexpr uint32_t shuf_fixed_lds_bytes(uint32_t sq) { return 4u * (16u + SHUF_R
 // LDS16 = true : segments of n_lo < n <= n_hi <= 65536 rows, kept in LDS as 16-bit local indices (one launch per size class,
 //                so that short chains are not held to the occupancy of the longest)
 // LDS16 = false: segments with n > n_lo rows, shuffled in place in global memory (32-bit)
-// PHASE 0: the whole chain.  Keyed chains of the longest size class are cut in two launches instead: the last SHUF_TAIL
-// steps of a chain are mostly conflicts and settles (the chance of a conflict in a group of 64 steps is ~6000 / i) and
-// cost far more than their share of the steps, while the chain holds a whole CU's LDS and its other roles have little left
-// to do.  PHASE 1 runs the steps n-1 .. SHUF_TAIL (the cut is a mask boundary, where C's batches end exactly anyway), writes
-// the order out (final above the cut, the SHUF_TAIL positions below it as they stand) and leaves the number of 32-bit
-// draws used in the first digest word of the chain; PHASE 2 reloads those local rows (16 KB of LDS: five chains per CU,
-// which hide each other's latencies), continues the random stream from that count and finishes the low positions.
-template <bool LDS16, uint32_t SHUF_SQ, int PHASE = 0>
+// TOP = 0, STOP = 1: the whole chain.  Keyed chains of the longest size class are cut into launches instead.  The chance
+// of a conflict in a group of 64 steps is ~6000 / i, so the low end of a chain is mostly conflicts and settles and costs far
+// more than its share of the steps; and a step never touches a position above its own, so the part of the segment that
+// still matters shrinks with i -- yet the chain holds a whole CU's LDS, one chain per CU, every role a single wavefront
+// bound by its own latencies.  A launch <TOP, STOP> runs the steps TOP-1 .. STOP of every chain (TOP = 0: from n-1, on the
+// identity): it loads the TOP low positions as the previous launch left them (16-bit local rows, from the loc stream) and
+// the number of 32-bit draws used so far (left in the chain's first digest word), continues the random stream from that
+// count, and writes out the positions below TOP -- final above STOP, as they stand below.  Cuts are powers of two: mask
+// boundaries, where C's batches end exactly anyway.  With one cut at 8192 the second launch holds five chains per CU,
+// which hide each other's latencies.
+template <bool LDS16, uint32_t SHUF_SQ, uint32_t TOP = 0, uint32_t STOP = 1>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
                    int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi,
@@ -101,11 +107,13 @@ __global__ void __launch_bounds__(256)
     if (n == 0) return;
     if (n <= n_lo || (LDS16 && n > n_hi)) return;  // this launch serves the chains with n_lo < n <= n_hi (its LDS is sized for n_hi)
     volatile uint32_t *x32 = (volatile uint32_t *)xg;
-    static_assert(PHASE == 0 || LDS16, "the two-phase form is for LDS-resident keyed chains");
-    if (PHASE != 0 && (dig_out == nullptr || s >= n_slots)) return;
+    constexpr bool FROM_STREAM = TOP != 0u, CUT = STOP > 1u;
+    static_assert(!(FROM_STREAM || CUT) || LDS16, "the cut form is for LDS-resident keyed chains");
+    static_assert((TOP & (TOP - 1u)) == 0u && (STOP & (STOP - 1u)) == 0u && (TOP == 0u || TOP > STOP), "cuts are powers of two");
+    if ((FROM_STREAM || CUT) && (dig_out == nullptr || s >= n_slots)) return;
     const uint32_t n_rows = n;                  // rows of the segment (local rows are < n_rows)
-    if (PHASE == 2) n = SHUF_TAIL;              // this launch sees the chain's low SHUF_TAIL positions only
-    const uint32_t stop_i = PHASE == 1 ? SHUF_TAIL : 1u;  // the chain runs while i >= stop_i
+    if (FROM_STREAM) n = TOP;                   // this launch sees the chain's low TOP positions only
+    const uint32_t stop_i = STOP;               // the chain runs while i >= stop_i
 
     // keyed form: the queue order goes out as {digest, 16-bit row} streams (offsim_shuffle_queues_keys)
     const bool keyed = LDS16 && dig_out != nullptr && s < n_slots;
@@ -147,10 +155,10 @@ __global__ void __launch_bounds__(256)
 
     if (threadIdx.x < 16u) ctrl[threadIdx.x] = threadIdx.x == SH_ATOP ? n - 1u : (threadIdx.x == SH_EM0 || threadIdx.x == SH_EM1) ? n_chunks : 0u;
     if (threadIdx.x < 64u) win[threadIdx.x] = 0;
-    uint32_t c_start = 0;  // PHASE 2: 32-bit draws the first phase used
-    if (PHASE == 2) {  // the low positions as the first phase left them, and its draw count
+    uint32_t c_start = 0;  // 32-bit draws the launches before this one used
+    if (FROM_STREAM) {  // the low positions as the previous launch left them, and its draw count
         c_start = dg[0];
-        for (uint32_t k = threadIdx.x; k < SHUF_TAIL; k += 256u) x16[k] = lc[k];
+        for (uint32_t k = threadIdx.x; k < TOP; k += 256u) x16[k] = lc[k];
     } else if (LDS16) {  // identity, two entries per lane and store
         __attribute__((address_space(3))) uint32_t *xw = (__attribute__((address_space(3))) uint32_t *)x16;
         for (uint32_t k = threadIdx.x; 2u * k < n; k += 256u) xw[k] = ((2u * k + 1u) << 16) | (2u * k);
@@ -321,7 +329,7 @@ __global__ void __launch_bounds__(256)
                     sh_st(ctrl + SH_CPUB, c);
                 }
             }
-            if (PHASE == 1) sh_st(ctrl + SH_CSTOP, c);  // (the cut is a mask boundary: i == SHUF_TAIL - 1 here, c counts from the stream's start)
+            if (CUT) sh_st(ctrl + SH_CSTOP, (c_start & ~1u) + c);  // (the cut is a mask boundary: i == STOP - 1 here; draws from the stream's start)
             sh_st(ctrl + SH_DONE, 1u);
         } else {
             // ---------------- A: apply, 64 consecutive steps i_top, i_top - 1, ... per iteration (lane l: step i_top - l).
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(256)
             }
         }
     }
-    if (PHASE == 1) {  // (behind the write-out of chunk 0, which holds this word)
+    if (CUT) {  // (behind the write-out of chunk 0, which holds this word)
         __syncthreads();
         if (threadIdx.x == 0) dg[0] = ctrl[SH_CSTOP];
     }
