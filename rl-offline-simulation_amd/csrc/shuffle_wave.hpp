@@ -133,6 +133,15 @@ __global__ void __launch_bounds__(256)
             const uint32_t k = k0 + 64u * (uint32_t)u;
             two[u] = k < pairs ? xw[k] : 0u;
         }
+        if (CUT && ch < STOP / SHUF_CH) {  // positions below the cut are not final: only their rows go out, for the next launch
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + 64u * (uint32_t)u;
+                lc[2u * k] = (uint16_t)(two[u] & 0xffffu);
+                lc[2u * k + 1u] = (uint16_t)(two[u] >> 16);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i1 = two[u] >> 16;  // (the slot behind an odd-length segment still holds its identity value n)
