@@ -269,7 +269,6 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     const int64_t n_blocks = (int64_t)(t->n_slots + 1) * n_perm;
     if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG>), 160 * 1024));
-    HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG, 0, SHUF_CUT>), 160 * 1024));
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_SMALL>), 160 * 1024));
     if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
         hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
@@ -289,16 +288,22 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
         const uint32_t sq = k == 0 ? SHUF_SQ_BIG : SHUF_SQ_SMALL;
         const size_t lds16 = shuf_fixed_lds_bytes(sq) + (((size_t)need * 2 + 15) & ~(size_t)15) + 16;
         if (k == 0 && dig_out) {
-            // keyed chains of the longest class in two launches (shuffle_wave.hpp, <TOP, STOP>): the steps above 8192 with the whole
-            // segment in LDS, then the conflict-ridden low end with 16 KB per chain, five chains per CU; the init queue (never
-            // keyed) keeps the one-launch form
-            hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_BIG, 0, SHUF_CUT>), dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots,
-                               t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
-            LAUNCH_CHECK();
-            const size_t lds_tail = shuf_fixed_lds_bytes(SHUF_SQ_SMALL) + (size_t)SHUF_CUT * 2 + 16;
-            hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_SMALL, SHUF_CUT, 1>), dim3((unsigned)n_blocks), dim3(256), lds_tail, st, t->seg_off,
-                               t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
-            LAUNCH_CHECK();
+            // keyed chains of the longest class in three launches (shuffle_wave.hpp, <TOP, STOP>): the steps above 16384 with the
+            // whole segment in LDS, then 16383 .. 4096 with 32 KB per chain (three chains per CU), then the conflict-ridden low end
+            // with 8 KB (seven per CU); the init queue (never keyed) keeps the one-launch form
+#define SHUF_LAUNCH(SQ, TOP, STOP, LDSB)                                                                                              \
+    do {                                                                                                                              \
+        HIP_TRY(allow_big_lds((k_shuffle_wave<true, SQ, TOP, STOP>), 160 * 1024));                                                     \
+        hipLaunchKernelGGL((k_shuffle_wave<true, SQ, TOP, STOP>), dim3((unsigned)n_blocks), dim3(256), (LDSB), st, t->seg_off, t->n_slots, \
+                           t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);                     \
+        LAUNCH_CHECK();                                                                                                               \
+    } while (0)
+#define SHUF_TAILB(TOP) (shuf_fixed_lds_bytes(SHUF_SQ_SMALL) + (size_t)(TOP) * 2 + 16)
+            SHUF_LAUNCH(SHUF_SQ_BIG, 0, SHUF_CUT_HI, lds16);
+            SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_HI, SHUF_CUT_LO, SHUF_TAILB(SHUF_CUT_HI));
+            SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_LO, 1, SHUF_TAILB(SHUF_CUT_LO));
+#undef SHUF_LAUNCH
+#undef SHUF_TAILB
             if (init_in)  // (an init queue of this size class: its chains are not keyed)
                 hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_BIG>), dim3((unsigned)n_perm), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N,
                                    t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, nullptr, nullptr);

@@ -34,10 +34,12 @@ namespace offsim {
 // partners in the j ring (power of two, >= 3 * 128), a template parameter (as a kernel argument it cost 3.5 %): 4096 for the class of the longest LDS-resident
 // chains (deep enough that C rarely waits behind a slow group of A; there one chain fills a CU anyway), 1024 elsewhere (the
 // short chains of a skewed table share a CU, and their occupancy is what the fixed part of the LDS costs)
-// cut of the keyed chains of the longest size class (see k_shuffle_wave).  Measured per pass of the headline job: uncut
-// 0.645 s; one cut at 2048 / 4096 / 8192 / 16384: 0.604 / 0.580 / 0.559 / 0.563 s; cuts at 32768 and 8192: 0.582 s; at
-// 8192 and 2048: 0.569 s
-#define SHUF_CUT 8192u
+// cuts of the keyed chains of the longest size class (see k_shuffle_wave).  Measured per pass of the headline job
+// (tools/time_reset.py ... keyed): uncut 0.645 s; one cut at 4096 / 8192 / 16384 / 32768: 0.575 / 0.548 / 0.540 / 0.568 s;
+// two cuts at 16384 + 4096: 0.528 s, 16384 + 2048: 0.529 s; three cuts at 16384 + 4096 + 1024: 0.535 s, 32768 + 8192 + 2048:
+// 0.536 s, 16384 + 8192 + 2048: 0.538 s, 32768 + 16384 + 4096: 0.552 s
+#define SHUF_CUT_HI 16384u
+#define SHUF_CUT_LO 4096u
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
@@ -73,8 +75,8 @@ constexpr uint32_t shuf_fixed_lds_bytes(uint32_t sq) { return 4u * (16u + SHUF_R
 // identity): it loads the TOP low positions as the previous launch left them (16-bit local rows, from the loc stream) and
 // the number of 32-bit draws used so far (left in the chain's first digest word), continues the random stream from that
 // count, and writes out the positions below TOP -- final above STOP, as they stand below.  Cuts are powers of two: mask
-// boundaries, where C's batches end exactly anyway.  With one cut at 8192 the second launch holds five chains per CU,
-// which hide each other's latencies.
+// boundaries, where C's batches end exactly anyway.  With cuts at 16384 and 4096 the launches hold one, three and seven
+// chains per CU; the chains of a CU hide each other's latencies.
 template <bool LDS16, uint32_t SHUF_SQ, uint32_t TOP = 0, uint32_t STOP = 1>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
