@@ -96,6 +96,9 @@ def test_randomised_queue_lengths_shuffle_equals_numpy_generator_shuffle():
         pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
     g = np.random.default_rng(int(os.environ.get("OFFSIM_FUZZ_SEED", "11")))
     lengths = [int(x) for x in g.integers(1, 65537, 24)] + [int(x) for x in g.integers(1, 700, 12)] + [65535, 65536, 65537, 70001, 131073]
+    # keyed chains above 32768 rows run as three launches cut at steps 16384 and 4096: lengths that leave the first launch one
+    # step, exactly one group, one group and a step, ...
+    lengths += [32769, 32768 + 63, 32768 + 64, 32768 + 65, 36864, 49152, 49153, 65472, 65473]
     for n in lengths:
         e = synth.synth_iid(n, 1, 2, seed=n)
         table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
