@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liboffsim_hip.so")
+# OFFSIM_LIB: another build of the same sources (A/B timing of kernel variants, the -DOFFSIM_ROWS_PROF / -DSHUF_FAULT_INJECT builds)
+LIB_PATH = os.environ.get("OFFSIM_LIB") or os.path.join(_HERE, "csrc", "liboffsim_hip.so")
 
 OK = 0
 F32, F64, F16 = 0, 1, 2

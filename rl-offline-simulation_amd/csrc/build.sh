@@ -6,4 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I../../include \
  -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
  -Wall -Wno-unused-function -Wno-int-to-pointer-cast"
-$HIPCC $FLAGS "$@" -o liboffsim_hip.so offsim_hip.hip
+# OUT=variants/libX.so build.sh -DFLAG ...  builds a variant next to the product library (A/B timing, profiling builds)
+OUT=${OUT:-liboffsim_hip.so}
+mkdir -p "$(dirname "$OUT")"
+$HIPCC $FLAGS "$@" -o "$OUT" offsim_hip.hip

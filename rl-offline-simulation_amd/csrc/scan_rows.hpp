@@ -7,15 +7,22 @@
 // counter, cursors) is a VGPR value that is uniform inside a 16-lane row, cross-lane steps are DPP row operations, and
 // a CU runs its 16 rollouts on 4 wavefronts (one per SIMD) at single-wavefront latency.
 //
-// The step itself has ONE LDS round trip on the chain (scan_win.hpp: two -- cursor pair, then the window row):
+// The step itself has ONE LDS round trip on the chain (scan_win.hpp: two -- cursor pair, then the window row), and FOUR LDS
+// instructions (entry read, draw read, row store, log store): on gfx950 a DS instruction holds the issuing wavefront for 16
+// cycles (a dense 64-lane ds_read_b32: 8), an ordinary VALU / SALU instruction for 4.4, a not-taken branch for ~10
+// (tools/micro/issue.hip), so the step is priced by its instruction mix, not by its dependent chain:
 //   * windows are HEAD-ALIGNED: entry j of a state's 8-entry row is the j-th candidate still queued (0 = none loaded).
 //     Accepting entry k pushes entries k+1.. to the front with one ds_write (lane j stores to slot (j-k-1) mod 8, the
-//     vacated slots get 0), so the next look at that state needs no cursor to find its candidates;
+//     vacated slots get 0), so the next look at that state needs no cursor to find its candidates -- and the chain keeps
+//     NO cursor at all: a state's queue position is land[s] (the position behind its window, which only refills move)
+//     minus the entries the window holds.  The step log is one dword (state left | done << 10 | candidates consumed), the
+//     tick turns it into queue positions (a segmented prefix sum over the tick's steps, per state) for the reward pipeline;
 //   * entries are stored BIASED, digest - 16 units of T21 (0 if that is negative), and the ring holds the draws as
-//     k21 << 11 | 1: then "draw <= entry" (one v_sub_co, its borrow) is a CLEAR accept -- the candidate's threshold is
+//     k21 << 11 | 0x7ff: then "draw <= entry" (one v_sub_co, its borrow) is a CLEAR accept -- the candidate's threshold is
 //     above the draw by 16 units or more -- and "entry < draw <= entry + 17 units" (one v_cmp on the difference) marks the
 //     lanes that need the exact 53-bit look.  Lanes 0..7 of a row test draw c+j against entry j; the first clear accept
-//     and its payload (done, z_next) come out of a 4-step DPP min over key = (j+1) << 28 | done << 10 | z_next;
+//     and its payload (done, z_next) come out of a 3-step DPP min over key = (j+1) << 26 | done << 10 | z_next (byte 3 of
+//     the key is then 4 x the candidates consumed: the draw counter and the row shift take it as an SDWA operand);
 //   * anything else -- a lane near a tie anywhere in the wavefront, no clear accept in a row, window dry, episode end,
 //     draws running low -- is an event: the hand-scheduled loop is left, every row that has an event goes through
 //     handle() (exact, reads the stream directly) while the rows without one commit their step; all rows therefore take
@@ -39,40 +46,63 @@ namespace offsim {
 #define ROWS_TICK 16u
 #define ROWS_RING 256u
 #define ROWS_W 8u
-#define ROWS_EMPTY 0u      // window slot without a candidate (a draw is never <= 0: ring entries carry a set low bit)
+#define ROWS_EMPTY 0u      // window slot without a candidate (a draw is never <= 0: ring entries have their low eleven bits set)
 #define ROWS_BIAS 0x8000u  // window entries are digest - 16 units of T21: "draw <= entry" is then a CLEAR accept
 #define ROWS_NOT_LANDED 0xffffffffu  // no digest has this value: the next-state field of a digest is < 0x3ff
 #define ROWS_AMB 0xffff7800u  // entry - draw >= this (i.e. the draw exceeds the entry by at most 17 units): the exact look decides
 // per-rollout LDS region (byte offsets); window rows are 32-byte aligned, the region a multiple of 512
-#define RO_RING 0u       // 256 draws, k21 << 11 | 1: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
+#define RO_RING 0u       // 256 draws, k21 << 11 | 0x7ff: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
 #define RO_INIT 1024u    // ring of 32 upcoming initial states (slot or -1), entry k of the queue at (k - first) & 31
-#define RO_LOG 1152u     // 16 x {cursor behind the accepted candidate, state left | done << 10}
+#define RO_LOG 1152u     // 16 step-log words: state left | done << 10 | candidates consumed (rows_log_k)
 #define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
-#define RO_POP RO_LOG2   // 16 x candidates popped by the step (TRACE, which is never a HELPER build)
 #define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
-enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24, SY_REQ = 28,  // byte offsets in RO_SYNC
-       SY_INITP = 32, SY_LEFT = 36 };  // chain loop: LDS address of the row's next initial state, episode ends it may still serve itself
+enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24, SY_REQ = 28 };  // byte offsets in RO_SYNC
+#define ROWS_LIF 26u      // the key's lane field: (lane + 1) << 26, so that byte 3 of a key = 4 x candidates consumed
+// step-log word: bits 0..9 state left, bit 10 done, and the candidates the step consumed -- 1..8 in bits 26..29 (what the
+// chain loop writes: its key, masked) or, with bit 31 set, any count in bits 11..30 (the exact path: a step can run through
+// many rejected candidates)
+#define ROWS_LOG_KMASK 0x3c000000u
+__device__ __forceinline__ uint32_t rows_log_word(uint32_t s, uint32_t done_bit, uint32_t k) { return s | done_bit | (k << 11) | 0x80000000u; }
+__device__ __forceinline__ uint32_t rows_log_k(uint32_t e) { return (e >> 31) ? ((e >> 11) & 0xfffffu) : (e >> 26); }
 #define ROWS_SPIN_LIMIT (1u << 22)  // polls (with s_sleep) before a hand-off wait gives up: ~2 s, never reached unless the protocol is broken
-#define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots], land[n_slots], claim[n_slots]
+#define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots] u32, land[n_slots] u32, claim[n_slots] u8
 
 typedef __attribute__((address_space(3))) volatile uint32_t ldsv_u32;
 typedef __attribute__((address_space(3))) volatile scan_u32x2 ldsv_u32x2;
 typedef __attribute__((address_space(3))) volatile double ldsv_f64;
+typedef uint32_t scan_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile scan_u32x4 ldsv_u32x4;
 #define LV32(a) (*(ldsv_u32 *)(a))
 #define LV64(a) (*(ldsv_u32x2 *)(a))
+#define LV128(a) (*(ldsv_u32x4 *)(a))
+typedef __attribute__((address_space(3))) volatile uint8_t ldsv_u8;
+#define LV8(a) (*(ldsv_u8 *)(a))
+// entries a head-aligned window row holds (the non-empty ones come first)
+__device__ __forceinline__ uint32_t rows_held(scan_u32x4 h0, scan_u32x4 h1) {
+    return (h0.x != 0u) + (h0.y != 0u) + (h0.z != 0u) + (h0.w != 0u) + (h1.x != 0u) + (h1.y != 0u) + (h1.z != 0u) + (h1.w != 0u);
+}
 
-__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 44u + 1023u) & ~1023u; }
+__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 41u + 1023u) & ~1023u; }  // 8 KiB at 162 states
 
 // Per-wavefront landing area of the tick's global loads.  They are issued as LDS-DMA (global_load_lds_dword: no VGPR
 // destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
-enum { DS_RQ0 = 0, DS_RQ1, DS_RQ2, DS_RQ3, DS_LOC, DS_GPLO, DS_GPHI, DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */,
-       DS_RQD = 11 /* HELPER: the request each lane made (position | state << 17 | entries << 27) */, DS_SLOTS = 12 };
-#define ROWS_DMA_BYTES 3072u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
+// (the two request areas hold FOUR dwords per lane each, lane l's at base + 16 l: one global_load_lds_dwordx4 fills an area)
+enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */, DS_LOC = 8, DS_GPLO, DS_GPHI,
+       DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */, DS_RQD = 15 /* the request each lane made (position | state << 17 | entries << 27) */,
+       DS_SLOTS = 16 };
+#ifndef ROWS_RQ_MAX
+#define ROWS_RQ_MAX 8u  // entries a top-up asks for at most (4: the second request area stays unused)
+#endif
+#define ROWS_DMA_BYTES 4096u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
                               // the draw ring's address is formed with an OR)
 
-__device__ __forceinline__ uint32_t rows_bias(uint32_t dig) { return dig >= ROWS_BIAS ? dig - ROWS_BIAS : 0u; }
+// A window entry is never ROWS_EMPTY (the entries a window holds are counted: that is the chain's only cursor): a digest at or
+// below the bias -- a candidate that is never a CLEAR accept -- becomes ROWS_NEVER, which no draw is <= (a ring entry's low
+// eleven bits are all set, a payload's never are) and which still lies within the exact look's band of every draw it could accept.
+#define ROWS_NEVER 0x200u
+__device__ __forceinline__ uint32_t rows_bias(uint32_t dig) { return dig > ROWS_BIAS ? dig - ROWS_BIAS : ROWS_NEVER; }
 
 __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst_uniform) {
     uint32_t keep;
@@ -81,6 +111,20 @@ __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+// four consecutive dwords per lane: lane l's land at lds_dst_uniform + 16 l
+__device__ __forceinline__ void lds_dma_x4(const void *gptr, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gptr), "s"(lds_dst_uniform)
@@ -158,7 +202,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t li4w = (li & 7u) * 4u;
     const uint32_t win_rd_l = win_a + li4w;
     const uint32_t ring_a = rbase + RO_RING;
-    const uint32_t lifield = ((li & 7u) + 1u) << 28;
+    const uint32_t lifield = ((li & 7u) + 1u) << ROWS_LIF;
 
     __syncthreads();
     auto seg_at = [&](uint32_t s) -> uint32_t { return LV32(seg_a + s * 4u); };
@@ -182,10 +226,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         for (uint32_t e = 0; e < ROWS_W; e++) LV32(win_a + s * 32u + e * 4u) = e < want ? rows_bias(dbase[beg + c0 + e]) : ROWS_EMPTY;
         LV32(cons_a + s * 4u) = c0;
         LV32(land_a + s * 4u) = c0 + want;
-        LV32(claim_a + s * 4u) = 0u;
+        LV8(claim_a + s) = 0u;
     }
 
-    // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of k21 << 11 | 1 ----
+    // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of k21 << 11 | 0x7ff ----
     const bool owns_draws = HELPER ? is_helper : true;
     U128 lane_state = u128(0, 0);
     U128 plus16 = u128(0, 0);
@@ -197,7 +241,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const U128 mult16 = u128(0xb6a4239f3b315f84ull, 0xf6ef6d3d288c03c1ull);  // PCG multiplier ** 16 mod 2**128
     uint32_t gen = 0, c = 0;  // draws generated (HELPER chain: known to be generated) / consumed since kernel start
     auto gen16 = [&]() {
-        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = ((uint32_t)(pcg_output(lane_state) >> 43) << 11) | 1u;
+        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = ((uint32_t)(pcg_output(lane_state) >> 43) << 11) | 0x7ffu;
         lane_state = add128(mul128(mult16, lane_state), plus16);
         gen += 16u;
     };
@@ -268,7 +312,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // ---- per-row state ----
     uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
     uint32_t z = 0;  // current state slot
-    uint32_t pop_acc = 0;    // candidates popped so far by the step in progress (TRACE)
     uint32_t n_dry = 0, n_tie = 0, n_tick = 0;
     // refill: one outstanding request per lane
     uint32_t rq_s = 0, rq_p = 0, rq_n = 0;
@@ -299,15 +342,18 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     };
     if (!dead && !is_helper) do_reset(0u);
 
-    // chain registers: w = this lane's window entry of the current state, kt = its draw, cz = the state's cursor
-    uint32_t vrow_w = 0, vcons = 0, w = 0, kt = 0, cz = 0;
+    // chain registers: w = this lane's window entry of the current state (read from ra), kt = its draw
+    uint32_t ra = 0, w = 0, kt = 0;
     auto issue_reads = [&]() {
         const uint32_t zz = dead ? 0u : z;
-        vrow_w = win_a + zz * 32u;
-        vcons = cons_a + zz * 4u;
-        w = LV32(vrow_w + li4w);
-        cz = LV32(vcons);
+        ra = win_a + zz * 32u + li4w;
+        w = LV32(ra);
         kt = LV32(ring_a + (((c << 2) + li4w) & (ROWS_RING * 4u - 4u)));
+    };
+    // entries the window of the row's current state holds (head-aligned: they come first), from the look's entries
+    auto held = [&](uint32_t wv) -> uint32_t {
+        const uint64_t b = __ballot(wv != ROWS_EMPTY);
+        return (uint32_t)__popc((uint32_t)(b >> (rw * 16u)) & 0xffu);
     };
     // the look of the hand-scheduled loop, restated for the iterations that run outside it (some row of the wavefront has
     // stopped, or TRACE): key as there, amb = some lane of the row needs the exact look
@@ -320,24 +366,16 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // the step's bookkeeping for a clear accept of window entry k1-1 with payload `key`
     auto commit = [&](uint32_t key, uint32_t k1, uint32_t it) {
         c += k1;
-        const uint32_t cz1 = cz + k1;
-        LV32(vcons) = cz1;
-        scan_u32x2 e;
-        e.x = cz1;
-        e.y = z | (key & 0x400u);
-        LV64(log_a + it * 8u) = e;
-        if (TRACE) {
-            LV32(rbase + RO_POP + it * 4u) = pop_acc + k1;
-            pop_acc = 0;
-        }
+        LV32(log_a + it * 4u) = rows_log_word(z, key & 0x400u, k1);
         const uint32_t k1x4 = k1 << 2;
-        LV32(((li4w - k1x4) & 28u) | vrow_w) = li4w < k1x4 ? ROWS_EMPTY : w;  // (lanes 8..15 repeat the stores of lanes 0..7)
+        LV32(((li4w - k1x4) & 28u) | (ra - li4w)) = li4w < k1x4 ? ROWS_EMPTY : w;  // (lanes 8..15 repeat the stores of lanes 0..7)
         z = key & 0x3ffu;
     };
 
-    // exact path: candidates of state z straight from the stream, starting at queue position cz, until one is accepted
-    // (completes the step: log, cursor, window = the candidates behind it) or the queue ends (the rollout stops)
-    auto direct = [&](uint32_t it) {
+    // exact path: candidates of state z straight from the stream, starting at queue position cz (`popped` candidates of the
+    // step are consumed already), until one is accepted (completes the step: log, window = the candidates behind it, land) or
+    // the queue ends (the rollout stops)
+    auto direct = [&](uint32_t it, uint32_t cz, uint32_t popped) {
         for (;;) {
             const uint32_t beg = seg_at(z), len = seg_at(z + 1u) - beg;
             if (len == 0u) {  // KeyError (psrs.py:44)
@@ -351,12 +389,21 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 status = OFFSIM_ST_EXHAUSTED;
                 dead = 1u;
                 nlog_dead = it;
-                LV32(cons_a + z * 4u) = cz;
+                if (li < 8u) LV32(win_a + z * 32u + li4) = ROWS_EMPTY;  // everything the window held is consumed: cursor = land
+                LV32(land_a + z * 4u) = cz;
                 return;
             }
             need_draws(16u, it);
             if (dead) return;
-            const uint32_t nv = rem < 16u ? rem : 16u;
+            // candidates up to the end of the 64-byte sector the head lies in: the window's last top-up came out of that sector, so it
+            // is still in L2 / the Infinity Cache (a read of 16 would nearly always reach into the next one: an HBM round trip for
+            // candidates the step rarely gets to); the batches behind an all-rejected one are whole sectors
+#ifndef ROWS_DIRECT_WHOLE
+            const uint32_t in_sector = 16u - ((uint32_t)((uintptr_t)(dbase + beg + cz) >> 2) & 15u);
+#else
+            const uint32_t in_sector = 16u;
+#endif
+            const uint32_t nv = rem < in_sector ? rem : in_sector;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
             const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> 11;
@@ -369,22 +416,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (fk == 0xffffffffu) {  // all of them rejected: consumed (one draw each)
                 c += nv;
                 cz += nv;
-                if (TRACE) pop_acc += nv;
+                popped += nv;
                 continue;
             }
             const uint32_t acc = fk & 0x7ffu;
             const uint32_t k1 = (fk >> 11) + 1u;
             c += k1;
             const uint32_t cz1 = cz + k1;
-            LV32(cons_a + z * 4u) = cz1;
-            scan_u32x2 e;
-            e.x = cz1;
-            e.y = z | (acc & 0x400u);
-            LV64(log_a + it * 8u) = e;
-            if (TRACE) {
-                LV32(rbase + RO_POP + it * 4u) = pop_acc + k1;
-                pop_acc = 0;
-            }
+            LV32(log_a + it * 4u) = rows_log_word(z, acc & 0x400u, popped + k1);
             const uint32_t keep = nv - k1 < ROWS_W ? nv - k1 : ROWS_W;  // the candidates behind it become the window
             if (li < 8u) LV32(win_a + z * 32u + li4) = ROWS_EMPTY;
             if (li >= k1 && li < k1 + keep) LV32(win_a + z * 32u + ((li - k1) << 2)) = rows_bias(dg);
@@ -398,27 +437,31 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
     };
 
+    // the look did not give the row a clear accept.  A lane near a tie: the exact look starts at the head of the queue, which is
+    // land - (entries held); what the window rejected is rejected again, with the same draws.  No lane near a tie: every
+    // candidate the window holds is a clear reject (or it holds none), they are consumed and the exact look starts behind them.
+    auto exact_step = [&](uint32_t it, bool amb) {
+        const uint32_t hv = held(w), ld = LV32(land_a + z * 4u);
+        if (amb) {
+            n_tie++;
+            direct(it, ld - hv, 0u);
+        } else {
+            n_dry++;
+            c += hv;
+            direct(it, ld, hv);
+        }
+    };
+
     // one iteration of a live row outside the hand-scheduled loop
     auto slow_step = [&](uint32_t key, bool amb, uint32_t it) {
         if (key != 0xffffffffu && !amb) {  // clear accept: the row's event, if any, is the episode end or low draws
-            commit(key, key >> 28, it);
+            commit(key, (key >> ROWS_LIF) & 15u, it);
             if (key & 0x400u) {
                 ep++;
                 do_reset(it + 1u);
             }
         } else {
-            uint32_t nrej = 0;  // with a lane near a tie the exact look starts at the head of the queue
-            if (!amb) {         // every candidate the window holds is a clear reject
-                const uint32_t v = LV32(land_a + z * 4u) - cz;
-                nrej = v < ROWS_W ? v : ROWS_W;
-                n_dry++;
-            } else {
-                n_tie++;
-            }
-            c += nrej;
-            cz += nrej;
-            if (TRACE) pop_acc += nrej;
-            direct(it);
+            exact_step(it, amb);
         }
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);  // enough for the rest of the tick (looks of <= 8)
     };
@@ -483,11 +526,36 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
         PF_PH(4);
     };
-    // second half: R2 and R1 issue this tick's loads
-    auto rewards_b = [&](uint32_t n, scan_u32x2 le, uint32_t pop_i) {
+    // Queue position of the candidate every step of the tick accepted, lane = step: the cursor of the state the step left, plus
+    // the candidates the tick's EARLIER steps consumed in that state (a prefix sum over the lanes of the row that hold the same
+    // state: row_shr by 1..15, a lane without a source keeps a state nobody has), plus its own, minus one.  The cursors then move
+    // on (ds_max: they only grow, so the order in which the lanes of one state arrive does not matter).
+    auto positions = [&](uint32_t n, uint32_t e) -> uint32_t {
         const bool mine = li < n;
-        const uint32_t s_i = le.y & 0x3ffu, pos_i = le.x - 1u;
-        const bool done_i = mine && (le.y & 0x400u);
+        const uint32_t s_i = mine ? (e & 0x3ffu) : 0xfffffffeu, k_i = mine ? rows_log_k(e) : 0u;
+        uint32_t pre = 0;
+#define ROWS_SHR(D)                                                                                                                   \
+        {                                                                                                                             \
+            const uint32_t sj = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)s_i, 0x110 + (D), 0xf, 0xf, false);      \
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k_i, 0x110 + (D), 0xf, 0xf, false);                    \
+            pre += sj == s_i ? kj : 0u;                                                                                               \
+        }
+        ROWS_SHR(1) ROWS_SHR(2) ROWS_SHR(3) ROWS_SHR(4) ROWS_SHR(5) ROWS_SHR(6) ROWS_SHR(7) ROWS_SHR(8)
+        ROWS_SHR(9) ROWS_SHR(10) ROWS_SHR(11) ROWS_SHR(12) ROWS_SHR(13) ROWS_SHR(14) ROWS_SHR(15)
+#undef ROWS_SHR
+        uint32_t pos = 0;
+        if (mine) {
+            const uint32_t ca = cons_a + s_i * 4u;
+            pos = LV32(ca) + pre + k_i - 1u;
+            asm volatile("ds_max_u32 %0, %1" ::"v"(ca), "v"(pos + 1u) : "memory");
+        }
+        return pos;
+    };
+    // second half: R2 and R1 issue this tick's loads
+    auto rewards_b = [&](uint32_t n, uint32_t e_i, uint32_t pos_i) {
+        const bool mine = li < n;
+        const uint32_t s_i = e_i & 0x3ffu, pop_i = rows_log_k(e_i);
+        const bool done_i = mine && (e_i & 0x400u);
         // R2: rewards of the steps of one tick ago (row = segment start + local row, the latter from the loc stream)
         {
             if (li < n1) {
@@ -551,23 +619,25 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         PF_PH(6);
     };
 
-    // A: one request per state left in the tick (the lane that holds the step tops the state up): up to four entries behind the
-    // window's end, as LDS-DMA into this pair's RQ slots.  Returns what it asked for (0 = nothing).
+    // A: one request per state left in the tick (the lane that holds the step tops the state up): the entries behind the
+    // window's end that the window has room for NOW (it is counted as it stands: the chain may have been there again since the
+    // step was logged), as one or two 16-byte LDS-DMA loads into this pair's request areas.  Returns what it asked for
+    // (0 = nothing).  (The loads fetch whole groups of four; a request that would read beyond the table's last row is left to
+    // the exact path.)
     auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) {
         q_n = 0;
-        if (mine) LV32(claim_a + s_i * 4u) = li;
-        if (mine && LV32(claim_a + s_i * 4u) == li) {
-            const uint32_t cs = LV32(cons_a + s_i * 4u), ld = LV32(land_a + s_i * 4u);
+        if (mine) LV8(claim_a + s_i) = (uint8_t)li;
+        if (mine && LV8(claim_a + s_i) == li) {
+            const scan_u32x4 h0 = LV128(win_a + s_i * 32u), h1 = LV128(win_a + s_i * 32u + 16u);
+            const uint32_t ld = LV32(land_a + s_i * 4u);
             const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
-            const uint32_t have = ld - cs, room = have < ROWS_W ? ROWS_W - have : 0u, left = len - ld;
+            const uint32_t room = ROWS_W - rows_held(h0, h1), left = len - ld;
             uint32_t want = room < left ? room : left;
-            want = want < 4u ? want : 4u;
-            if (want) {
+            want = want < ROWS_RQ_MAX ? want : ROWS_RQ_MAX;
+            if (want && (int64_t)beg + ld + 8 <= t.N) {
                 const uint32_t *src = dbase + beg + ld;
-                lds_dma_dword(src, dma_a + DS_RQ0 * 256u);
-                if (want > 1u) lds_dma_dword(src + 1, dma_a + DS_RQ1 * 256u);
-                if (want > 2u) lds_dma_dword(src + 2, dma_a + DS_RQ2 * 256u);
-                if (want > 3u) lds_dma_dword(src + 3, dma_a + DS_RQ3 * 256u);
+                lds_dma_x4(src, dma_a + DS_RQA * 256u);
+                if (want > 4u) lds_dma_x4(src + 4, dma_a + DS_RQB * 256u);
                 q_s = s_i;
                 q_p = ld;
                 q_n = want;
@@ -605,25 +675,28 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads of the previous tick
             // The chain has read the RQ slots of the previous round (before it published this tick): mark them "not landed".
             // The helper never waits for the digests it requests; the chain lands what has arrived (it has, a tick later).
-            LV32(dma_a + DS_RQ0 * 256u + lane * 4u) = ROWS_NOT_LANDED;
-            LV32(dma_a + DS_RQ1 * 256u + lane * 4u) = ROWS_NOT_LANDED;
-            LV32(dma_a + DS_RQ2 * 256u + lane * 4u) = ROWS_NOT_LANDED;
-            LV32(dma_a + DS_RQ3 * 256u + lane * 4u) = ROWS_NOT_LANDED;
+            {
+                const scan_u32x4 none = {ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED};
+                LV128(dma_a + DS_RQA * 256u + lane * 16u) = none;
+                LV128(dma_a + DS_RQB * 256u + lane * 16u) = none;
+            }
             const uint32_t la = rbase + ((k & 1u) ? RO_LOG2 : RO_LOG);
             const uint32_t n = LV32(sync_a + ((k & 1u) ? SY_N1 : SY_N0));
-            const scan_u32x2 le = LV64(la + li * 8u);
+            const uint32_t le = LV32(la + li4);
             fin = LV32(sync_a + SY_FIN);
             cp = LV32(sync_a + SY_C);
             LV32(sync_a + SY_HTICK) = k + 1u;  // (behind the reads of the buffer: the chain may reuse it)
-            {   // the window top-ups this tick's steps call for; the chain lands them at the end of its next tick
+            {   // the window top-ups this tick's steps call for, first of all (the chain lands them at the end of its next tick:
+                // what has not arrived by then is lost)
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
-                request(li < n, le.y & 0x3ffu, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
+                request(li < n, le & 0x3ffu, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
                 LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
+            const uint32_t pos_i = positions(n, le);
             PF_PH(9);
             rewards_a();
-            rewards_b(n, le, 0u);
+            rewards_b(n, le, pos_i);
             if (gen - cp < 240u) {
                 while (gen - cp < 240u) gen16();
                 LV32(sync_a + SY_GEN) = gen;
@@ -631,13 +704,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             PF_PH(10);
             if (__ballot(fin == 0u) == 0ull) break;  // every rollout of the wavefront has stopped: tick k was the last one
         }
-        scan_u32x2 none;
-        none.x = 0;
-        none.y = 0;
         for (int dr = 0; dr < 2; dr++) {  // drain the pipeline (R2, R3 of the last ticks)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             rewards_a();
-            rewards_b(0u, none, 0u);
+            rewards_b(0u, 0u, 0u);
         }
         if (fin == (uint32_t)OFFSIM_ST_EXHAUSTED + 1u) {  // psrs.py:265: the cut-short episode still logs its length
             if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
@@ -664,18 +734,16 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t n = dead ? nlog_dead : ROWS_TICK;
         nlog_dead = 0;
         n_tick++;
-        uint32_t in_d0 = 0, in_d1 = 0, in_d2 = 0, in_d3 = 0, v_ht = 0, v_gen = 0;
-        scan_u32x2 le;
-        le.x = 0;
-        le.y = 0;
-        uint32_t pop_i = 0;
+        scan_u32x4 in_a = {0u, 0u, 0u, 0u}, in_b = {0u, 0u, 0u, 0u};
+        uint32_t v_ht = 0, v_gen = 0;
+        uint32_t le = 0;
         if (HELPER) {
             // One batch of reads: the flag of the helper's request round (it made the requests of the PREVIOUS tick's steps while
             // this tick ran), the descriptors and digests of that round, and the two counters the next tick needs.  A flag that
             // is not there yet is rare (the helper is a tick ahead); only then are the reads repeated behind a bounded wait.
             const uint32_t v_req = LV32(sync_a + SY_REQ);
             uint32_t dsc = dma_slot(DS_RQD);
-            in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+            in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
             v_ht = LV32(sync_a + SY_HTICK);
             v_gen = LV32(sync_a + SY_GEN);
             if (tick_k >= 1u) {
@@ -686,25 +754,26 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                         dead = 1u;
                     }
                     dsc = dma_slot(DS_RQD);
-                    in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+                    in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
                 }
                 rq_p = dsc & 0x1ffffu;
                 rq_s = (dsc >> 17) & 0x3ffu;
-                rq_n = dsc >> 27;
+                rq_n = dsc >> 27;  // (<= 8)
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
-            le = LV64(log_a + li * 8u);
-            if (TRACE) pop_i = LV32(rbase + RO_POP + li4);
-            in_d0 = dma_slot(DS_RQ0), in_d1 = dma_slot(DS_RQ1), in_d2 = dma_slot(DS_RQ2), in_d3 = dma_slot(DS_RQ3);
+            le = LV32(log_a + li4);
+            in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
         }
         PF_PH(0);
         // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
-        // covered meanwhile is skipped, whatever does not fit -- or has not arrived -- is requested again later.
-        uint32_t land_cs = 0, land_ld = 0;
+        // covered meanwhile is skipped, whatever does not fit -- or has not arrived -- is requested again later.  The window is
+        // head-aligned, so its end is the number of entries it holds.
+        uint32_t land_have = 0, land_ld = 0;
         if (rq_n) {
-            land_cs = LV32(cons_a + rq_s * 4u);
+            const scan_u32x4 h0 = LV128(win_a + rq_s * 32u), h1 = LV128(win_a + rq_s * 32u + 16u);
             land_ld = LV32(land_a + rq_s * 4u);
+            land_have = rows_held(h0, h1);
         }
         if (HELPER) {
             // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
@@ -716,34 +785,32 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             LV32(sync_a + SY_TICK) = tick_k + 1u;
         }
         PF_PH(1);
-        if (__ballot(rq_n != 0u && rq_p != land_ld) == 0ull) {
-            // every request of the wavefront starts at its window's end (no direct read in between, the usual case): the
-            // first k entries land, k = what was asked for, has arrived and fits; the other stores go to a scratch word
-            const uint32_t have = land_ld - land_cs;
-            uint32_t k = in_d0 == ROWS_NOT_LANDED ? 0u : in_d1 == ROWS_NOT_LANDED ? 1u : in_d2 == ROWS_NOT_LANDED ? 2u : in_d3 == ROWS_NOT_LANDED ? 3u : 4u;
-            k = k < rq_n ? k : rq_n;
-            const uint32_t room = have < ROWS_W ? ROWS_W - have : 0u;
-            k = k < room ? k : room;
-            const uint32_t dst = win_a + rq_s * 32u + (have << 2);
-            const uint32_t scratch = sync_a + 64u + li4;  // (the hand-off words end at 40)
-            LV32(k > 0u ? dst : scratch) = rows_bias(in_d0);
-            LV32(k > 1u ? dst + 4u : scratch) = rows_bias(in_d1);
-            LV32(k > 2u ? dst + 8u : scratch) = rows_bias(in_d2);
-            LV32(k > 3u ? dst + 12u : scratch) = rows_bias(in_d3);
-            if (rq_n) LV32(land_a + rq_s * 4u) = land_ld + k;
-            rq_n = 0;
-        } else if (rq_n) {
-            const uint32_t cs = land_cs;
-            uint32_t ld = land_ld;
-            const uint32_t dd[4] = {in_d0, in_d1, in_d2, in_d3};
-#pragma unroll
-            for (uint32_t e = 0; e < 4u; e++) {
-                if (e < rq_n && dd[e] != ROWS_NOT_LANDED && rq_p + e == ld && ld - cs < ROWS_W) {
-                    LV32(win_a + rq_s * 32u + ((ld - cs) << 2)) = rows_bias(dd[e]);
-                    ld++;
-                }
+        {
+            // A request lands where it was aimed at -- the window's end; one that a direct read has overtaken meanwhile is dropped
+            // (the state is topped up again when it is next left).  Of what was asked for, the groups of four that have arrived
+            // land as far as the window has room; the other stores go to a scratch word.
+            const bool hit = rq_n != 0u && rq_p == land_ld;
+            const bool got_a = in_a.x != ROWS_NOT_LANDED && in_a.y != ROWS_NOT_LANDED && in_a.z != ROWS_NOT_LANDED && in_a.w != ROWS_NOT_LANDED;
+            uint32_t k = !hit ? 0u : !got_a ? 0u : rq_n < 4u ? rq_n : 4u;
+            if (ROWS_RQ_MAX > 4u) {
+                const bool got_b = in_b.x != ROWS_NOT_LANDED && in_b.y != ROWS_NOT_LANDED && in_b.z != ROWS_NOT_LANDED && in_b.w != ROWS_NOT_LANDED;
+                k = (k == 4u && got_b) ? rq_n : k;
             }
-            LV32(land_a + rq_s * 4u) = ld;
+            const uint32_t room = ROWS_W - land_have;
+            k = k < room ? k : room;
+            const uint32_t dst = win_a + rq_s * 32u + (land_have << 2);
+            const uint32_t scratch = sync_a + 64u + li4;  // (the hand-off words end at 32)
+            LV32(k > 0u ? dst : scratch) = rows_bias(in_a.x);
+            LV32(k > 1u ? dst + 4u : scratch) = rows_bias(in_a.y);
+            LV32(k > 2u ? dst + 8u : scratch) = rows_bias(in_a.z);
+            LV32(k > 3u ? dst + 12u : scratch) = rows_bias(in_a.w);
+            if (ROWS_RQ_MAX > 4u && __ballot(k > 4u) != 0ull) {
+                LV32(k > 4u ? dst + 16u : scratch) = rows_bias(in_b.x);
+                LV32(k > 5u ? dst + 20u : scratch) = rows_bias(in_b.y);
+                LV32(k > 6u ? dst + 24u : scratch) = rows_bias(in_b.z);
+                LV32(k > 7u ? dst + 28u : scratch) = rows_bias(in_b.w);
+            }
+            if (k) LV32(land_a + rq_s * 4u) = land_ld + k;
             rq_n = 0;
         }
         PF_PH(2);
@@ -766,9 +833,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
             PF_PH(7);
         } else {
-            request(li < n, le.y & 0x3ffu, rq_s, rq_p, rq_n);
+            const uint32_t pos_i = positions(n, le);
+            request(li < n, le & 0x3ffu, rq_s, rq_p, rq_n);
             rewards_a();
-            rewards_b(n, le, pop_i);
+            rewards_b(n, le, pos_i);
             if (!dead) {
                 prefetch_step();
                 while (gen - c < 240u) gen16();
@@ -781,176 +849,179 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // One iteration = one accepted step of every live row.  fast_run() is the hand-scheduled loop: nothing but the
     // clear-accept path, left through one wave-uniform branch as soon as ANY lane of the wavefront sees something else; that
     // iteration is then redone row by row (rows without an event commit, the others take the exact path), and the loop is
-    // entered again.  TRACE builds and wavefronts with a stopped row run every iteration the second way.
+    // entered again.  Rows that have stopped are masked out of the loop (exec), the others keep its pace; TRACE builds run every
+    // iteration the second way.
     //
-    // Instruction order inside the loop: the draw of the NEXT look is requested as soon as the number of consumed candidates
-    // is known (its ring address needs nothing else); the window entry and the cursor of the next state are requested
-    // behind this step's three LDS stores (cursor, shifted row, log), because the next state may be this one.
     // what the loop hands over when it is left for an event: the look's key, the lanes that need the exact look, and the
     // stores of the step as the loop had prepared them (valid for the rows whose look was a clear accept)
-    uint32_t ex_key = 0, ex_d = 0, ex_slot = 0, ex_cz1 = 0, ex_k4 = 0;
+    uint32_t ex_key = 0, ex_d = 0, ex_slot = 0;
     uint64_t ex_amb = 0;
-    auto fast_run = [&](uint32_t &it) {
+    auto fast_run = [&](uint32_t &it, uint64_t live) {
         // episode ends the loop may serve itself: after this many the episode cap, the end of the init queue or the end of
         // what is stored in the ring is reached and the C++ path has to look
         const uint32_t initp0 = init_a + (((ic - ic0) & 31u) << 2);
+        uint32_t initp = initp0, left = filled - ic;
         {
-            uint32_t left = filled - ic;
             left = left < N0 - ic ? left : N0 - ic;  // (ic <= N0)
             const uint32_t cap = ep + 1u < max_episodes ? max_episodes - ep - 1u : 0u;
             left = left < cap ? left : cap;
-            LV32(sync_a + SY_INITP) = initp0;
-            LV32(sync_a + SY_LEFT) = left;
         }
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
-        uint32_t zz = z, logaddr = log_a + it * 8u - 8u;
-        uint32_t key, k4, d, tt, nrd, zn, cz1, vconsn, w2;
+        uint32_t zz = z;
+        uint32_t key, d, tt, nrd, e, zn, rb, w2;
         uint64_t amb, ev;
-        // One copy of the step; the loop body is four of them (the taken branch of the back edge is paid once per four steps).
-        // The step's time is the time from the arrival of the look's entry and draw to the ISSUE of the next look's two reads,
-        // plus the LDS latency: everything that is not needed for those two addresses (the 16-lane minimum over the keys, then
-        // one shift for the entry and shift + add + mask for the draw) is placed behind them, in the shadow of that latency.
-        // The next entry is read ahead of this step's stores -- if the next state is this state (vcc) it is read again behind
-        // them, out of line -- into the other of two registers (w / w2), since this step still needs its own; the cursor of
-        // the next state is read behind the stores and waited for only where it is used.  A VALU result is not consumed by the
-        // next instruction where that can be avoided, and a DPP operand is two instructions old.
-        // The state of a row (zz, vcons) is not copied at the end of a step either: odd copies take it from (zz, vcons) and
-        // leave the next one in (zn, vconsn), even copies the other way round; the exits put it where the C++ code expects it.
-#define ROWS_STEP(FIX, EPI, BACK, ZZ, VC, ZN, VCN, W, WN)                                                                     \
-            "s_waitcnt lgkmcnt(1)\n\t"                                   /* this look's entry and draw, the last step's stores (its cursor read may be out) */ \
-            "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */ \
-            "v_and_or_b32 %[key], " W ", %[s7ff], %[lif]\n\t"            /* (lane + 1) << 28 | done << 10 | z_next */ \
-            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"                                                               \
+        // One copy of the step; the loop body is the sixteen steps of a tick, copy i writing log word i (immediate offset), so
+        // there is neither a step counter nor a back edge, and the loop is entered at copy `it` through a branch table.
+        // What a step costs is the sum of what its instructions hold the wavefront for (tools/micro/issue.hip: VALU / SALU 4.4
+        // cycles, three-operand VALU 5.3, a DS instruction 16, a branch not taken ~10), so the step is made of as few of them as
+        // the algorithm allows, four DS instructions among them: the next draw's read (its address needs only the number of
+        // candidates consumed), the row store, the next entry's read BEHIND it (the next state may be this one) and the log
+        // word.  The chain keeps no cursor: a queue position is land - (entries held), worked out where it is needed (tick,
+        // exact path).  The one branch of a step leaves for every event at once: a lane near a tie, a row without a clear
+        // accept, the end of an episode.
+        // The state of a row (zz = state, ra = the address its entry was read from, w = the entry) is not copied at the end of a
+        // step: even copies take it from (zz, ra, w) and leave the next one in (zn, rb, w2), odd copies the other way round;
+        // the entry code fills both sets, the exits put it where the C++ code expects it.
+#define ROWS_STEP(LOGOFF, EPI, BACK, ZZ, RA, W, ZN, RN, WN)                                                                   \
+            BACK ":\n\t"                                                                                                  \
+            "s_waitcnt lgkmcnt(0)\n\t"                                   /* this look's entry and draw */                \
+            "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */                \
+            "v_and_or_b32 %[key], " W ", %[s7ff], %[lif]\n\t"            /* (lane + 1) << 26 | done << 10 | z_next */    \
             "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
-            "v_add_u32 %[logaddr], 8, %[logaddr]\n\t"                                                                     \
+            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"              /* (two instructions behind the one that wrote vcc, two ahead of the DPP read) */ \
+            "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
-            "s_nop 0\n\t"                                                                                                 \
+            "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
             "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
-            "v_lshl_add_u32 %[nrd], %[key], 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
-            "v_lshrrev_b32 %[k4], 26, %[key]\n\t"                        /* 4 x candidates consumed by this step */     \
-            "ds_read_b32 " WN ", %[nrd]\n\t"                             /* next look's entry */                         \
-            "v_add_u32 %[c4], %[c4], %[k4]\n\t"                                                                           \
             "v_and_b32 " ZN ", %[s7ff], %[key]\n\t"                      /* next state (| done << 10: an event) */      \
+            "v_add_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
+            "v_cmp_lt_u32_e64 %[ev], %[srmask], " ZN "\n\t"              /* episode end, or the all-ones key of a row without a clear accept (states are < 0x3fc) */ \
+            "v_sub_co_u32_sdwa %[tt], vcc, %[li4w], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
             "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
-            "v_sub_co_u32 %[tt], vcc, %[li4w], %[k4]\n\t"               /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
             "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
             "v_cndmask_b32_e64 %[d], " W ", 0, vcc\n\t"                                                                   \
-            "v_cmp_lt_u32_e64 %[ev], %[srmask], " ZN "\n\t"              /* episode end, or the all-ones key of a row without a clear accept (states are < 0x3fc) */ \
-            "v_lshrrev_b32 %[cz1], 28, %[key]\n\t"                                                                        \
-            "v_cmp_eq_u32_e64 vcc, " ZN ", " ZZ "\n\t"                   /* next state == this state: its entry is read again behind the stores */ \
-            "v_lshl_add_u32 " VCN ", " ZN ", 2, %[consa]\n\t"                                                             \
-            "s_waitcnt lgkmcnt(2)\n\t"                                   /* this state's cursor */                       \
-            "v_add_u32 %[cz1], %[cz1], %[cz]\n\t"                        /* cursor behind the accepted candidate */     \
-            "v_and_or_b32 %[tt], %[tt], 28, %[vrow]\n\t"                                                                  \
+            "v_bfi_b32 %[tt], 28, %[tt], " RA "\n\t"                     /* its address in this state's row */           \
+            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
             "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
             "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
             /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
-            "ds_write_b32 " VC ", %[cz1]\n\t"                                                                             \
-            "ds_write2_b32 %[logaddr], %[cz1], " ZZ " offset1:1\n\t"     /* {cursor behind the accepted candidate, state left} */ \
-            "ds_write_b32 %[tt], %[d]\n\t"                                                                                \
-            "ds_read_b32 %[cz], " VCN "\n\t"                             /* next state's cursor (behind the stores: right also if it is this state) */ \
-            "s_cmp_lg_u64 vcc, 0\n\t"                                                                                     \
-            "v_lshl_add_u32 %[vrow], " ZN ", 5, %[wina]\n\t"                                                              \
-            "s_cbranch_scc1 " FIX "f\n\t"                                                                                 \
-            BACK ":\n\t"
+            "ds_write_b32 %[tt], %[d]\n\t"                               /* the row, shifted */                          \
+            "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (behind the store: right also if it is this state) */ \
+            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"              /* log word: state left | candidates consumed << 26 */ \
+            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"
         /* Out of line: the only event of the look is the end of an episode in some rows (psrs.py:249-269: env.reset() pops */   \
-        /* the shuffled init queue).  The row's next initial states wait in its LDS ring; SY_LEFT says how many the loop may */  \
+        /* the shuffled init queue).  The row's next initial states wait in its LDS ring; `left` says how many the loop may   */  \
         /* take before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed with */ \
-        /* the log word marked "done", the next state of those rows is their next initial state. */                           \
-#define ROWS_EPI(EPI, BACK, OUT, ZZ, VC, ZN, VCN, W, WN)                                                                  \
+        /* the log word marked "done", the next state of those rows is their next initial state. */
+#define ROWS_EPI(LOGOFF, EPI, BACK, OUT, ZZ, RA, W, ZN, RN, WN)                                                           \
             EPI ":\n\t"                                                                                                    \
             "s_cmp_lg_u64 %[amb], 0\n\t"                                                                                   \
             "s_cbranch_scc1 " OUT "f\n\t"                               /* a lane needs the exact look */                  \
             "v_cmp_le_u32_e32 vcc, 0x500, " ZN "\n\t"                   /* all-ones key: a row without a clear accept */   \
             "s_cbranch_vccnz " OUT "f\n\t"                                                                                 \
             "v_cmp_le_u32_e32 vcc, 0x400, " ZN "\n\t"                   /* vcc: the rows whose episode ends */             \
-            "ds_read_b32 " W ", %[rsync] offset:36\n\t"                 /* (this look's entry register and cz are free) */ \
-            "ds_read_b32 %[cz], %[rsync] offset:32\n\t"                                                                    \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-            "v_cmp_eq_u32_e64 %[ev], 0, " W "\n\t"                                                                         \
+            "v_cmp_eq_u32_e64 %[ev], 0, %[left]\n\t"                                                                       \
+            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"                                                                \
             "s_and_b64 %[ev], %[ev], vcc\n\t"                                                                              \
             "s_cbranch_scc1 " OUT "f\n\t"                               /* a row may not take another reset here */       \
-            "ds_read_b32 " VCN ", %[cz]\n\t"                            /* the next initial state */                      \
-            "v_subrev_u32 " W ", 1, " W "\n\t"                                                                             \
-            "v_add_u32 %[cz], 4, %[cz]\n\t"                                                                                \
-            "v_and_b32 %[cz], 0xffffff7f, %[cz]\n\t"                   /* the ring of 32 is 128-byte aligned: wrap */    \
-            "v_or_b32 %[nrd], 0x400, " ZZ "\n\t"                        /* log word of an episode end */                  \
             "s_mov_b64 exec, vcc\n\t"                                                                                      \
-            "ds_write_b32 %[rsync], " W " offset:36\n\t"                                                                   \
-            "ds_write_b32 %[rsync], %[cz] offset:32\n\t"                                                                   \
-            "s_mov_b64 exec, -1\n\t"                                                                                       \
-            "v_cndmask_b32_e32 %[nrd], " ZZ ", %[nrd], vcc\n\t"                                                            \
-            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
-            "v_cndmask_b32_e32 " ZN ", " ZN ", " VCN ", vcc\n\t"                                                           \
-            "ds_write_b32 " VC ", %[cz1]\n\t"                                                                              \
-            "ds_write2_b32 %[logaddr], %[cz1], %[nrd] offset1:1\n\t"                                                       \
+            "ds_read_b32 " ZN ", %[initp]\n\t"                          /* the next initial state */                      \
+            "v_subrev_u32 %[left], 1, %[left]\n\t"                                                                         \
+            "v_add_u32 %[initp], 4, %[initp]\n\t"                                                                          \
+            "v_or_b32 %[e], 0x400, %[e]\n\t"                            /* log word of an episode end */                  \
+            "v_and_b32 %[initp], 0xffffff7f, %[initp]\n\t"              /* the ring of 32 is 128 bytes at a 256-byte boundary: wrap */ \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                  \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                 \
-            "v_lshl_add_u32 " VCN ", " ZN ", 2, %[consa]\n\t"                                                              \
-            "v_lshl_add_u32 %[vrow], " ZN ", 5, %[wina]\n\t"                                                               \
-            "s_nop 0\n\t"                                                                                                  \
-            "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                       \
-            "ds_read_b32 " WN ", %[nrd]\n\t"                                                                               \
-            "ds_read_b32 %[cz], " VCN "\n\t"                                                                               \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"                                                             \
+            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
+            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"                                                               \
+            "ds_read_b32 " WN ", " RN "\n\t"                                                                               \
             "s_branch " BACK "b\n\t"
-#define ROWS_FIX(FIX, BACK, WN)                                                                                           \
-            FIX ":\n\t"                                                   /* some row stays in its state: its entry again, behind the stores */ \
-            "v_add_u32 %[nrd], %[vrow], %[li4w]\n\t"                                                                      \
-            "ds_read_b32 " WN ", %[nrd]\n\t"                                                                              \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "s_branch " BACK "b\n\t"
-#define RA "%[zz]", "%[vcons]", "%[zn]", "%[vconsn]", "%[w]", "%[w2]"
-#define RB "%[zn]", "%[vconsn]", "%[zz]", "%[vcons]", "%[w2]", "%[w]"
+        // an event the loop does not serve: nothing of copy I is committed, the row state goes where the C++ code expects it
+#define ROWS_OUT_A(OUT, I) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 2f\n\t"
+#define ROWS_OUT_B(OUT, I) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 22f\n\t"
+#define RA "%[zz]", "%[ra]", "%[w]", "%[zn]", "%[rb]", "%[w2]"
+#define RB "%[zn]", "%[rb]", "%[w2]", "%[zz]", "%[ra]", "%[w]"
 #define ROWS_STEP_(...) ROWS_STEP(__VA_ARGS__)
 #define ROWS_EPI_(...) ROWS_EPI(__VA_ARGS__)
         asm volatile(
-            "s_waitcnt lgkmcnt(0)\n\t"                                   // (the reads issue_reads() started)
-            "1:\n\t"
-            ROWS_STEP_("51", "71", "61", RA)
-            "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 41f\n\t"
-            ROWS_STEP_("52", "72", "62", RB)
-            "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 3f\n\t"
-            ROWS_STEP_("53", "73", "63", RA)
-            "s_cmp_eq_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 41f\n\t"
-            ROWS_STEP_("54", "74", "64", RB)
-            "s_cmp_lt_u32 %[it], 16\n\t"
-            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b64 s[24:25], exec\n\t"                               // rows that have stopped sit the loop out: nothing of theirs is read or written
+            "s_mov_b64 exec, %[live]\n\t"
+            "v_mov_b32 %[zn], %[zz]\n\t"                                 // both register sets hold the row state: any copy may be the first
+            "v_mov_b32 %[rb], %[ra]\n\t"
+            "v_mov_b32 %[w2], %[w]\n\t"
+            "s_cmp_eq_u32 %[it], 0\n\t"
+            "s_cbranch_scc1 100f\n\t"
+            "s_getpc_b64 s[20:21]\n\t"                                   // = the address of the next instruction; the table starts 20 bytes behind it
+            "s_lshl_b32 s22, %[it], 2\n\t"
+            "s_add_u32 s22, s22, 20\n\t"
+            "s_add_u32 s20, s20, s22\n\t"
+            "s_addc_u32 s21, s21, 0\n\t"
+            "s_setpc_b64 s[20:21]\n\t"
+            "s_branch 100f\n\t" "s_branch 101f\n\t" "s_branch 102f\n\t" "s_branch 103f\n\t"
+            "s_branch 104f\n\t" "s_branch 105f\n\t" "s_branch 106f\n\t" "s_branch 107f\n\t"
+            "s_branch 108f\n\t" "s_branch 109f\n\t" "s_branch 110f\n\t" "s_branch 111f\n\t"
+            "s_branch 112f\n\t" "s_branch 113f\n\t" "s_branch 114f\n\t" "s_branch 115f\n\t"
+            ROWS_STEP_("0", "200", "100", RA)
+            ROWS_STEP_("4", "201", "101", RB)
+            ROWS_STEP_("8", "202", "102", RA)
+            ROWS_STEP_("12", "203", "103", RB)
+            ROWS_STEP_("16", "204", "104", RA)
+            ROWS_STEP_("20", "205", "105", RB)
+            ROWS_STEP_("24", "206", "106", RA)
+            ROWS_STEP_("28", "207", "107", RB)
+            ROWS_STEP_("32", "208", "108", RA)
+            ROWS_STEP_("36", "209", "109", RB)
+            ROWS_STEP_("40", "210", "110", RA)
+            ROWS_STEP_("44", "211", "111", RB)
+            ROWS_STEP_("48", "212", "112", RA)
+            ROWS_STEP_("52", "213", "113", RB)
+            ROWS_STEP_("56", "214", "114", RA)
+            ROWS_STEP_("60", "215", "115", RB)
+            "116:\n\t"
+            "s_movk_i32 %[it], 16\n\t"                                   // the tick is over; copy 15 left the row state in (zz, ra, w)
             "s_branch 3f\n\t"
-            ROWS_FIX("51", "61", "%[w2]")
-            ROWS_FIX("52", "62", "%[w]")
-            ROWS_FIX("53", "63", "%[w2]")
-            ROWS_FIX("54", "64", "%[w]")
-            ROWS_EPI_("71", "61", "2", RA)
-            ROWS_EPI_("72", "62", "22", RB)
-            ROWS_EPI_("73", "63", "2", RA)
-            ROWS_EPI_("74", "64", "22", RB)
-            "41:\n\t"                                                    // the tick ended behind an odd copy
+            ROWS_EPI_("0", "200", "101", "300", RA)
+            ROWS_EPI_("4", "201", "102", "301", RB)
+            ROWS_EPI_("8", "202", "103", "302", RA)
+            ROWS_EPI_("12", "203", "104", "303", RB)
+            ROWS_EPI_("16", "204", "105", "304", RA)
+            ROWS_EPI_("20", "205", "106", "305", RB)
+            ROWS_EPI_("24", "206", "107", "306", RA)
+            ROWS_EPI_("28", "207", "108", "307", RB)
+            ROWS_EPI_("32", "208", "109", "308", RA)
+            ROWS_EPI_("36", "209", "110", "309", RB)
+            ROWS_EPI_("40", "210", "111", "310", RA)
+            ROWS_EPI_("44", "211", "112", "311", RB)
+            ROWS_EPI_("48", "212", "113", "312", RA)
+            ROWS_EPI_("52", "213", "114", "313", RB)
+            ROWS_EPI_("56", "214", "115", "314", RA)
+            ROWS_EPI_("60", "215", "116", "315", RB)
+            ROWS_OUT_A("300", "0") ROWS_OUT_B("301", "1") ROWS_OUT_A("302", "2") ROWS_OUT_B("303", "3")
+            ROWS_OUT_A("304", "4") ROWS_OUT_B("305", "5") ROWS_OUT_A("306", "6") ROWS_OUT_B("307", "7")
+            ROWS_OUT_A("308", "8") ROWS_OUT_B("309", "9") ROWS_OUT_A("310", "10") ROWS_OUT_B("311", "11")
+            ROWS_OUT_A("312", "12") ROWS_OUT_B("313", "13") ROWS_OUT_A("314", "14") ROWS_OUT_B("315", "15")
+            "22:\n\t"                                                    // event in an odd copy: its state is in (zn, rb, w2)
             "v_mov_b32 %[zz], %[zn]\n\t"
-            "v_mov_b32 %[vcons], %[vconsn]\n\t"
-            "s_branch 3f\n\t"
-            "22:\n\t"                                                    // event in an even copy: its state is in (zn, vconsn)
-            "v_mov_b32 %[zz], %[zn]\n\t"
-            "v_mov_b32 %[vcons], %[vconsn]\n\t"
+            "v_mov_b32 %[ra], %[rb]\n\t"
+            "v_mov_b32 %[w], %[w2]\n\t"
             "2:\n\t"
-            "v_sub_u32 %[c4], %[c4], %[k4]\n\t"                          // nothing of this iteration is committed
-            "s_sub_u32 %[it], %[it], 1\n\t"
+            "v_sub_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  // nothing of this iteration is committed
             "3:\n\t"
+            "s_mov_b64 exec, s[24:25]\n\t"
             "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
-            : [w] "+v"(w), [kt] "+v"(kt), [cz] "+v"(cz), [c4] "+v"(c4), [vrow] "+v"(vrow_w), [vcons] "+v"(vcons), [zz] "+v"(zz),
-              [logaddr] "+v"(logaddr), [key] "=&v"(key), [k4] "=&v"(k4), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd),
-              [zn] "=&v"(zn), [cz1] "=&v"(cz1), [vconsn] "=&v"(vconsn), [w2] "=&v"(w2), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
-            : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [wina] "v"(win_a), [consa] "v"(cons_a), [li4w] "v"(li4w),
-              [rsync] "v"(sync_a), [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [srmask] "s"(ROWS_RING * 4u - 4u)
-            : "vcc", "scc", "memory");
+            : [w] "+v"(w), [kt] "+v"(kt), [c4] "+v"(c4), [ra] "+v"(ra), [zz] "+v"(zz), [initp] "+v"(initp), [left] "+v"(left),
+              [key] "=&v"(key), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd), [e] "=&v"(e), [zn] "=&v"(zn), [rb] "=&v"(rb), [w2] "=&v"(w2),
+              [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
+            : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [li4w] "v"(li4w), [logb] "v"(log_a),
+              [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [srmask] "s"(ROWS_RING * 4u - 4u), [skm] "s"(ROWS_LOG_KMASK), [live] "s"(live)
+            : "vcc", "scc", "memory", "s20", "s21", "s22", "s24", "s25");
 #undef ROWS_STEP
-#undef ROWS_FIX
 #undef ROWS_EPI
+#undef ROWS_OUT_A
+#undef ROWS_OUT_B
 #undef ROWS_STEP_
 #undef ROWS_EPI_
 #undef RA
@@ -958,15 +1029,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         c = (c4 - li4w) >> 2;
         z = zz;
         {
-            const uint32_t served = ((LV32(sync_a + SY_INITP) - initp0) >> 2) & 31u;  // episode ends the loop served (the pointer wraps)
+            const uint32_t served = ((initp - initp0) >> 2) & 31u;  // episode ends the loop served (the pointer wraps)
             ic += served;
             ep += served;
         }
         ex_key = key;
         ex_d = d;
         ex_slot = tt;
-        ex_cz1 = cz1;
-        ex_k4 = k4;
         ex_amb = amb;
     };
     // the iteration the loop was left in, from what it handed over (no second look, no re-read of the window)
@@ -974,40 +1043,36 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t key = ex_key;
         const bool amb = ((uint32_t)(ex_amb >> (rw * 16u)) & 0xffffu) != 0u;
         if (key != 0xffffffffu && !amb) {  // clear accept: the stores the loop had prepared, then the episode end if that was the event
-            LV32(vcons) = ex_cz1;
-            scan_u32x2 e;
-            e.x = ex_cz1;
-            e.y = z | (key & 0x400u);
-            LV64(log_a + it * 8u) = e;
+            LV32(log_a + it * 4u) = (key & ROWS_LOG_KMASK) | z | (key & 0x400u);
             LV32(ex_slot) = ex_d;
-            c += ex_k4 >> 2;
+            c += (key >> ROWS_LIF) & 15u;
             z = key & 0x3ffu;
             if (key & 0x400u) {
                 ep++;
                 do_reset(it + 1u);
             }
         } else {
-            cz = ex_cz1 - (key >> 28);  // the cursor as it was before the look (the loop overwrote the register with its early read)
-            if (amb) n_tie++;           // exact look from the head of the queue: what the window rejected is rejected again, with the same draws
-            else n_dry++;
-            direct(it);
+            exact_step(it, amb);
         }
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);
     };
 
     if (!dead) need_draws(136u, 0u);  // (HELPER: the helper wavefront has filled the ring)
+    // shader cycles and 100 MHz ticks of the chain (out.dbg): the clock it ran at, and how the wavefronts' run times spread
+    const uint64_t pf_c0 = out.dbg ? __builtin_amdgcn_s_memtime() : 0ull, pf_r0 = out.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (uint32_t drained = 0;;) {
         uint32_t it = 0;
         if (drained) it = ROWS_TICK;  // every row has stopped: only the reward pipeline is still draining
         while (it < ROWS_TICK) {
             issue_reads();
-            if (!TRACE && __ballot(dead != 0u) == 0ull) {
+            const uint64_t live = __ballot(dead == 0u);
+            if (!TRACE && live != 0ull) {  // (rows that have stopped are masked out of the loop)
                 PF_START();
-                fast_run(it);
+                fast_run(it, live);
                 PF_ADD(pf_fast);
                 if (it == ROWS_TICK) break;
                 PF_START();
-                resume_step(it);
+                if (!dead) resume_step(it);
             } else {
                 PF_START();
                 uint32_t key = 0;
@@ -1026,13 +1091,23 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         PF_ADD(pf_tick);
         if (__ballot(!dead) == 0ull && (HELPER || ++drained == 3u)) break;  // (single wavefront: two more ticks drain the reward pipeline)
     }
+    const uint64_t pf_c1 = out.dbg ? __builtin_amdgcn_s_memtime() - pf_c0 : 0ull, pf_r1 = out.dbg ? __builtin_amdgcn_s_memrealtime() - pf_r0 : 0ull;
+#ifdef OFFSIM_ROWS_PROF
+    pf_ph[10] = pf_c1;
+    pf_ph[11] = pf_r1;
+#endif
     if (!HELPER && status == OFFSIM_ST_EXHAUSTED) {  // psrs.py:265: the cut-short episode still logs its length
         if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
         n_len++;
     }
     // ---- write the env state back ----
     if (r < (int64_t)ro.R) {
-        for (uint32_t s = li; s < n_slots; s += 16u) cur_glb[s] = LV32(cons_a + s * 4u);
+        for (uint32_t s = li; s < n_slots; s += 16u) {  // cursor = the position behind the window minus the entries it holds
+            const scan_u32x4 h0 = LV128(win_a + s * 32u), h1 = LV128(win_a + s * 32u + 16u);
+            const uint32_t hv = (h0.x != ROWS_EMPTY) + (h0.y != ROWS_EMPTY) + (h0.z != ROWS_EMPTY) + (h0.w != ROWS_EMPTY) +
+                                (h1.x != ROWS_EMPTY) + (h1.y != ROWS_EMPTY) + (h1.z != ROWS_EMPTY) + (h1.w != ROWS_EMPTY);
+            cur_glb[s] = LV32(land_a + s * 4u) - hv;
+        }
         if (li == 0u) {
             ro.init_cursor[r] = ic;
             ro.cur_slot[r] = (int32_t)z;
@@ -1063,8 +1138,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (out.dbg) {
                 out.dbg[4 * r + 0] = n_dry;
                 out.dbg[4 * r + 1] = n_tie;
-                out.dbg[4 * r + 2] = n_tick;
-                out.dbg[4 * r + 3] = gen / 16u;
+                out.dbg[4 * r + 2] = (int64_t)pf_c1;
+                out.dbg[4 * r + 3] = (int64_t)pf_r1;
             }
 #endif
         }
