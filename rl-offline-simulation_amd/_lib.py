@@ -51,11 +51,13 @@ class Column(C.Structure):
 
 class TD(C.Structure):
     """struct offsim_td"""
-    _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64), ("behaviour", _i32), ("epsilon", C.c_double)]
+    _fields_ = [("mode", _i32), ("alpha", C.c_double), ("q", _vp), ("td_err", _vp), ("td_cap", _i64), ("behaviour", _i32), ("epsilon", C.c_double),
+                ("alpha_ep", _vp), ("epsilon_ep", _vp), ("n_sched", _i64), ("q_snap", _vp), ("snap_cap", _i64), ("snap_stride", _i64),
+                ("tie_mt", _vp), ("beh_arg", _vp)]
 
 
 TD_QLEARN, TD_EXPSARSA = 1, 2
-BEHAVIOUR_FIXED, BEHAVIOUR_EPS_GREEDY = 0, 1
+BEHAVIOUR_FIXED, BEHAVIOUR_EPS_GREEDY, BEHAVIOUR_SOFT_GREEDY = 0, 1, 2
 
 # name -> (restype, argtypes): exactly the entry points include/offsim.h declares
 SIGNATURES = {
@@ -85,6 +87,7 @@ SIGNATURES = {
                                          C.POINTER(EvalMCOut), _vp]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
+    "offsim_selftest_lds_atomic_order": (C.c_int, [_vp, _vp]),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
     "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
 }

@@ -1129,6 +1129,49 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     return OFFSIM_OK;
 }
 
+// Self-test of the one hardware property csrc/scan_rows.hpp relies on beyond the ISA manual: the LDS applies the lanes of ONE
+// ds_add_rtn_u32 that hit the same address in ascending lane order, so that lane i gets back base + the addends of the lower
+// lanes with its address (the tick's queue positions are taken that way).  Random address patterns with 1 .. 162 distinct
+// addresses, lanes sitting out at random; *mismatches (device, int64) receives the number of lanes that got anything else.
+__global__ void k_selftest_lds_order(uint32_t seed0, int trials, uint32_t n_addr, unsigned long long *bad) {
+    __shared__ uint32_t cell[256];
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long nbad = 0;
+    uint32_t h = seed0 * 2654435761u + blockIdx.x * 97u + 1u;
+    for (int t = 0; t < trials; t++) {
+        for (uint32_t i = lane; i < 256; i += 64) cell[i] = 1000u * i;
+        __syncthreads();
+        h = h * 1664525u + 1013904223u;
+        const uint32_t hl = (h ^ (lane * 0x9e3779b9u)) * 2246822519u;
+        const uint32_t a = (hl >> 8) % n_addr, kk = 1u + ((hl >> 20) & 7u);
+        const bool active = ((hl >> 28) & 7u) != 0u;
+        uint32_t got = 0;
+        if (active) {
+            const uint32_t addr = (uint32_t)(uintptr_t)(offsim::lds_u32 *)&cell[a];
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(addr), "v"(kk) : "memory");
+        }
+        uint32_t want = 1000u * a;
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t aj = __shfl(a, j), kj = __shfl(kk, j);
+            const bool actj = __shfl((int)active, j);
+            if (j < lane && actj && aj == a) want += kj;
+        }
+        if (active && got != want) nbad++;
+        __syncthreads();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+extern "C" int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream) {
+    if (!mismatches) return fail(OFFSIM_EINVAL, "selftest: NULL output%s");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(mismatches, 0, sizeof(int64_t), st));
+    const uint32_t n_addr[] = {1u, 2u, 3u, 5u, 16u, 40u, 162u};
+    for (uint32_t n : n_addr) hipLaunchKernelGGL(k_selftest_lds_order, dim3(256), dim3(64), 0, st, 12345u + n, 500, n, (unsigned long long *)mismatches);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Encoders
 // ------------------------------------------------------------------------------------------------

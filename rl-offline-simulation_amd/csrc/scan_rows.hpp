@@ -89,13 +89,14 @@ __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { ret
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
 // (the two request areas hold FOUR dwords per lane each, lane l's at base + 16 l: one global_load_lds_dwordx4 fills an area)
-enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */, DS_LOC = 8, DS_GPLO, DS_GPHI,
-       DS_RLO, DS_RHI, DS_PROD /* two slots: 16 products per row */, DS_RQD = 15 /* the request each lane made (position | state << 17 | entries << 27) */,
-       DS_SLOTS = 16 };
+enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */, DS_LOC = 8,
+       DS_GP = 9 /* four slots: the discount factor of every lane's step (and the table entry behind it) */, DS_RLO = 13, DS_RHI,
+       DS_PROD /* two slots: 16 products per row */, DS_RQD = 17 /* the request each lane made (position | state << 17 | entries << 27) */,
+       DS_SLOTS = 18 };
 #ifndef ROWS_RQ_MAX
 #define ROWS_RQ_MAX 8u  // entries a top-up asks for at most (4: the second request area stays unused)
 #endif
-#define ROWS_DMA_BYTES 4096u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
+#define ROWS_DMA_BYTES 5120u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
                               // the draw ring's address is formed with an OR)
 
 // A window entry is never ROWS_EMPTY (the entries a window holds are counted: that is the chain's only cursor): a digest at or
@@ -191,6 +192,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this pair's DMA slots
     const uint32_t rbase = seg_a + seg_bytes + n_chain * ROWS_DMA_BYTES + rid * region_bytes;
     auto dma_slot = [&](uint32_t slot) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
+#define ROWS_READ_A() LV128(dma_a + DS_RQA * 256u + lane * 16u)
+
     const uint32_t win_a = rbase + RO_WIN, cons_a = win_a + n_slots * 32u, land_a = cons_a + n_slots * 4u, claim_a = land_a + n_slots * 4u;
     const uint32_t sync_a = rbase + RO_SYNC;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
@@ -312,13 +315,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // ---- per-row state ----
     uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
     uint32_t z = 0;  // current state slot
-    uint32_t n_dry = 0, n_tie = 0, n_tick = 0;
+    uint32_t n_dry = 0, n_tie = 0, n_tick = 0, n_late = 0, n_miss = 0, n_req = 0;
     // refill: one outstanding request per lane
     uint32_t rq_s = 0, rq_p = 0, rq_n = 0;
     // reward pipeline, three ticks deep (R1: row index + discount, R2: reward, R3: in-order sums)
     uint32_t rowb1 = 0, half1 = 0, pop1 = 0, n1 = 0, n2 = 0, dm1 = 0, dm2 = 0, st1 = 0;
     uint64_t any1 = 0, any2 = 0;
-    double gp2 = 0.0;
+    double gp2 = 0.0, gpx1 = 0.0;
+    bool bx1 = false;
     uint32_t tt_chain = 0, steps = 0, ep_acc = 0, n_len = 0, len_acc = 0;
     double G = 0.0, sum_g = 0.0;
 
@@ -483,8 +487,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // first half: what the previous tick's loads brought, and R3 (no new load is issued here)
     auto rewards_a = [&]() {
         in_loc = dma_slot(DS_LOC);
-        in_gplo = dma_slot(DS_GPLO);
-        in_gphi = dma_slot(DS_GPHI);
+        {
+            const scan_u32x4 gpq = LV128(dma_a + DS_GP * 256u + lane * 16u);
+            in_gplo = gpq.x;
+            in_gphi = gpq.y;
+        }
         const uint32_t in_rlo = dma_slot(DS_RLO), in_rhi = dma_slot(DS_RHI);
         PF_PH(3);
         // R3: in-order discounted-return accumulation (psrs.py:262-269) for the steps of two ticks ago: the products are
@@ -497,7 +504,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             *(ldsv_f64 *)(pa + li * 8u) = prod;
             double p[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) p[i] = *(ldsv_f64 *)(pa + (uint32_t)i * 8u);
+            for (int i = 0; i < 16; i += 2) {  // (two products per LDS read)
+                const scan_u32x4 q = LV128(pa + (uint32_t)i * 8u);
+                p[i] = __hiloint2double((int)q.y, (int)q.x);
+                p[i + 1] = __hiloint2double((int)q.w, (int)q.z);
+            }
             int32_t base_len = (int32_t)len_acc;  // length of the open episode minus the steps of this tick already counted
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -527,27 +538,17 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         PF_PH(4);
     };
     // Queue position of the candidate every step of the tick accepted, lane = step: the cursor of the state the step left, plus
-    // the candidates the tick's EARLIER steps consumed in that state (a prefix sum over the lanes of the row that hold the same
-    // state: row_shr by 1..15, a lane without a source keeps a state nobody has), plus its own, minus one.  The cursors then move
-    // on (ds_max: they only grow, so the order in which the lanes of one state arrive does not matter).
+    // the candidates the tick's EARLIER steps consumed in that state, plus its own, minus one -- and the cursors move on.  One LDS
+    // atomic does all of it: the LDS applies the lanes of a ds_add_rtn_u32 that hit one address in ascending lane order (= step
+    // order), so a lane gets back exactly the cursor as its step found it (tools/micro/lds_atomic_order.hip checks this on the
+    // hardware; offsim_selftest_lds_atomic_order is the same check behind the C ABI).
     auto positions = [&](uint32_t n, uint32_t e) -> uint32_t {
-        const bool mine = li < n;
-        const uint32_t s_i = mine ? (e & 0x3ffu) : 0xfffffffeu, k_i = mine ? rows_log_k(e) : 0u;
-        uint32_t pre = 0;
-#define ROWS_SHR(D)                                                                                                                   \
-        {                                                                                                                             \
-            const uint32_t sj = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)s_i, 0x110 + (D), 0xf, 0xf, false);      \
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k_i, 0x110 + (D), 0xf, 0xf, false);                    \
-            pre += sj == s_i ? kj : 0u;                                                                                               \
-        }
-        ROWS_SHR(1) ROWS_SHR(2) ROWS_SHR(3) ROWS_SHR(4) ROWS_SHR(5) ROWS_SHR(6) ROWS_SHR(7) ROWS_SHR(8)
-        ROWS_SHR(9) ROWS_SHR(10) ROWS_SHR(11) ROWS_SHR(12) ROWS_SHR(13) ROWS_SHR(14) ROWS_SHR(15)
-#undef ROWS_SHR
         uint32_t pos = 0;
-        if (mine) {
-            const uint32_t ca = cons_a + s_i * 4u;
-            pos = LV32(ca) + pre + k_i - 1u;
-            asm volatile("ds_max_u32 %0, %1" ::"v"(ca), "v"(pos + 1u) : "memory");
+        if (li < n) {
+            const uint32_t ca = cons_a + (e & 0x3ffu) * 4u, k_i = rows_log_k(e);
+            uint32_t pre;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pre) : "v"(ca), "v"(k_i) : "memory");
+            pos = pre + k_i - 1u;
         }
         return pos;
     };
@@ -558,23 +559,24 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const bool done_i = mine && (e_i & 0x400u);
         // R2: rewards of the steps of one tick ago (row = segment start + local row, the latter from the loc stream)
         {
-            if (li < n1) {
-                const uint32_t lc = lbase ? ((half1 ? in_loc >> 16 : in_loc) & 0xffffu) : in_loc;
-                const uint32_t g = rowb1 + lc;
-                if (r64) {
-                    const uint32_t *src = (const uint32_t *)((const double *)t.r + g);
-                    lds_dma_dword(src, dma_a + DS_RLO * 256u);
-                    lds_dma_dword(src + 1, dma_a + DS_RHI * 256u);
-                } else {
-                    lds_dma_dword((const float *)t.r + g, dma_a + DS_RLO * 256u);
-                }
-                if (TRACE) {
-                    const uint32_t st = st1 + li;
-                    if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[r * out.trace_cap + st] = t.orig_idx[g];
-                    if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[r * out.trace_cap + st] = pop1;
-                }
+            // (Every load of the pipeline is issued by every lane -- one without work reads the rollout's own stream state -- so
+            // that a round issues a FIXED number of vector-memory instructions: the helper's waits count them, ROWS_VM_*.)
+            const bool act = li < n1;
+            const uint32_t lc = lbase ? ((half1 ? in_loc >> 16 : in_loc) & 0xffffu) : in_loc;
+            const uint32_t g = rowb1 + lc;
+            if (r64) {
+                const uint32_t *src = act ? (const uint32_t *)((const double *)t.r + g) : (const uint32_t *)rng4;
+                lds_dma_dword(src, dma_a + DS_RLO * 256u);
+                lds_dma_dword(src + 1, dma_a + DS_RHI * 256u);
+            } else {
+                lds_dma_dword(act ? (const void *)((const float *)t.r + g) : (const void *)rng4, dma_a + DS_RLO * 256u);
             }
-            gp2 = __hiloint2double((int)in_gphi, (int)in_gplo);
+            if (TRACE && act) {
+                const uint32_t st = st1 + li;
+                if (out.trace_row && (int64_t)st < out.trace_cap) out.trace_row[r * out.trace_cap + st] = t.orig_idx[g];
+                if (out.trace_pop && (int64_t)st < out.trace_cap) out.trace_pop[r * out.trace_cap + st] = pop1;
+            }
+            gp2 = bx1 ? gpx1 : __hiloint2double((int)in_gphi, (int)in_gplo);
             dm2 = dm1;
             any2 = any1;
             n2 = n1;
@@ -584,28 +586,21 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         {
             const uint64_t bal = __ballot(done_i);
             const uint32_t dmrow = (uint32_t)(bal >> (rw * 16u)) & 0xffffu;  // episode ends of this row's tick
-            uint32_t rb = 0, hf = 0;
-            if (mine) {
-                rb = seg_at(s_i);
-                if (lbase) {
-                    const uint64_t a16 = (uint64_t)(uintptr_t)(lbase + rb + pos_i);
-                    hf = (uint32_t)(a16 >> 1) & 1u;
-                    lds_dma_dword((const void *)(uintptr_t)(a16 & ~3ull), dma_a + DS_LOC * 256u);
-                } else {
-                    LV32(dma_a + DS_LOC * 256u + lane * 4u) = pos_i;  // table order: the local row is the queue position
-                }
-                const uint32_t below = dmrow & ((1u << li) - 1u);  // episode ends earlier in this tick
-                const uint32_t t_i = below ? li - 1u - (31u - (uint32_t)__clz((int)below)) : tt_chain + li;
-                if ((uint64_t)t_i < n_gamma_pow) {
-                    const uint32_t *src = (const uint32_t *)(gamma_pow + t_i);
-                    lds_dma_dword(src, dma_a + DS_GPLO * 256u);
-                    lds_dma_dword(src + 1, dma_a + DS_GPHI * 256u);
-                } else {  // beyond the host's table (csrc/discount.hpp)
-                    const double gp = discount_beyond_table(gamma_pow, n_gamma_pow, gamma, (uint64_t)t_i);
-                    LV32(dma_a + DS_GPLO * 256u + lane * 4u) = (uint32_t)__double2loint(gp);
-                    LV32(dma_a + DS_GPHI * 256u + lane * 4u) = (uint32_t)__double2hiint(gp);
-                }
+            uint32_t hf = 0;
+            const uint32_t rb = mine ? seg_at(s_i) : 0u;
+            if (lbase) {
+                const uint64_t a16 = mine ? (uint64_t)(uintptr_t)(lbase + rb + pos_i) : (uint64_t)(uintptr_t)rng4;
+                hf = (uint32_t)(a16 >> 1) & 1u;
+                lds_dma_dword((const void *)(uintptr_t)(a16 & ~3ull), dma_a + DS_LOC * 256u);
+            } else if (mine) {
+                LV32(dma_a + DS_LOC * 256u + lane * 4u) = pos_i;  // table order: the local row is the queue position
             }
+            const uint32_t below = dmrow & ((1u << li) - 1u);  // episode ends earlier in this tick
+            const uint32_t t_i = below ? li - 1u - (31u - (uint32_t)__clz((int)below)) : tt_chain + li;
+            const bool in_table = mine && (uint64_t)t_i + 1u < n_gamma_pow;  // (one 16-byte load: the entry and the one behind it)
+            lds_dma_x4(in_table ? (const void *)(gamma_pow + t_i) : (const void *)rng4, dma_a + DS_GP * 256u);
+            bx1 = mine && !in_table;  // the table's last entry or beyond it (csrc/discount.hpp): worked out here, used in place of the slot
+            if (bx1) gpx1 = discount_at(gamma_pow, n_gamma_pow, gamma, (uint64_t)t_i);
             rowb1 = rb;
             half1 = hf;
             pop1 = pop_i;
@@ -626,30 +621,43 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // the exact path.)
     auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) {
         q_n = 0;
+        const uint32_t sa = mine ? s_i : 0u;  // (a lane without a step looks at state 0 and asks for nothing)
         if (mine) LV8(claim_a + s_i) = (uint8_t)li;
-        if (mine && LV8(claim_a + s_i) == li) {
-            const scan_u32x4 h0 = LV128(win_a + s_i * 32u), h1 = LV128(win_a + s_i * 32u + 16u);
-            const uint32_t ld = LV32(land_a + s_i * 4u);
-            const uint32_t beg = seg_at(s_i), len = seg_at(s_i + 1u) - beg;
-            const uint32_t room = ROWS_W - rows_held(h0, h1), left = len - ld;
-            uint32_t want = room < left ? room : left;
-            want = want < ROWS_RQ_MAX ? want : ROWS_RQ_MAX;
-            if (want && (int64_t)beg + ld + 8 <= t.N) {
-                const uint32_t *src = dbase + beg + ld;
-                lds_dma_x4(src, dma_a + DS_RQA * 256u);
-                if (want > 4u) lds_dma_x4(src + 4, dma_a + DS_RQB * 256u);
-                q_s = s_i;
-                q_p = ld;
-                q_n = want;
-            }
+        // one batch of reads, one wait: who holds the state's claim, the window as it stands, its end, the segment
+        const uint32_t cl = LV8(claim_a + sa);
+        const scan_u32x4 h0 = LV128(win_a + sa * 32u), h1 = LV128(win_a + sa * 32u + 16u);
+        const uint32_t ld = LV32(land_a + sa * 4u), beg = seg_at(sa), len = seg_at(sa + 1u) - beg;
+        const uint32_t room = ROWS_W - rows_held(h0, h1), left = len - ld;
+        uint32_t want = room < left ? room : left;
+        want = want < ROWS_RQ_MAX ? want : ROWS_RQ_MAX;
+        // (every lane issues the loads -- one that asks for nothing reads the rollout's own stream state into its slot, which
+        // nobody looks at: a round then issues a fixed number of vector-memory instructions, ROWS_VM_REQ)
+        const bool ok = mine && cl == li && want && (int64_t)beg + ld + 8 <= t.N;
+        const uint32_t *src = ok ? dbase + beg + ld : (const uint32_t *)rng4;
+        lds_dma_x4(src, dma_a + DS_RQA * 256u);
+        if (ROWS_RQ_MAX > 4u) lds_dma_x4(ok && want > 4u ? src + 4 : (const uint32_t *)rng4, dma_a + DS_RQB * 256u);
+        if (ok) {
+            q_s = s_i;
+            q_p = ld;
+            q_n = want;
         }
     };
 
     // ================================================ the helper wavefront (HELPER) ================================================
     if (is_helper) {
+        // The helper runs AHEAD of its chain wavefront on their SIMD (issue priority).  The chain's period without an exact-path
+        // stall (~5000 cycles) is barely longer than a helper round, and a helper that is still busy when a tick is published
+        // asks for that tick's top-ups late: on the XCDs with the longer memory latency 8 % of them then missed the next tick
+        // and the windows ran dry half again as often (measured; tools/clock_rows.py).  At priority the round is short enough
+        // everywhere; it costs the chain ~25 cycles per iteration of issue slots, which the steadier top-ups more than return.
+        __builtin_amdgcn_s_setprio(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LV32(sync_a + SY_GEN) = gen;  // the first 240 draws are in the ring
         uint32_t fin = 0;
+#ifdef ROWS_DIAG_LAG
+        double lag_sum = 0.0, lag_n = 0.0, lag_over = 0.0, lag_d1 = 0.0, lag_d2 = 0.0, lag_d3 = 0.0;
+        uint32_t lag_max = 0;
+#endif
 #ifdef OFFSIM_ROWS_PROF
         pf_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -659,22 +667,38 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             bool ok = false;
             for (uint32_t tries = 0; tries < ROWS_SPIN_LIMIT; tries++) {
                 const uint32_t tk = LV32(sync_a + SY_TICK);
+                if (__ballot(tk <= k) == 0ull) {  // (first of all: the tick's top-ups are waiting to be asked for)
+                    ok = true;
+                    break;
+                }
                 cp = LV32(sync_a + SY_C);
                 if (gen - cp < 240u) {
                     while (gen - cp < 240u) gen16();
                     LV32(sync_a + SY_GEN) = gen;  // (behind the ring entries: the LDS runs one wavefront's DS instructions in issue order)
                 }
-                if (__ballot(tk <= k) == 0ull) {
-                    ok = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(1);
             }
             if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
+#ifdef ROWS_DIAG_LAG
+            lag_d1 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
+#endif
             PF_PH(8);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads of the previous tick
+            // The request areas are free once the previous round's request loads have landed: they were that round's FIRST loads,
+            // so at most the ones issued behind them -- the reward pipeline's: reward (one or two dwords), local row, discount
+            // factor (one) -- may still be out.  (Vector-memory operations complete in issue order.)  Not waiting for those is
+            // what keeps the top-ups of this tick from queueing behind a slow reward load of the last one.
+            if (r64) {
+                if (lbase) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                if (lbase) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
             // The chain has read the RQ slots of the previous round (before it published this tick): mark them "not landed".
             // The helper never waits for the digests it requests; the chain lands what has arrived (it has, a tick later).
+#ifdef ROWS_DIAG_LAG
+            lag_d2 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
+#endif
             {
                 const scan_u32x4 none = {ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED};
                 LV128(dma_a + DS_RQA * 256u + lane * 16u) = none;
@@ -686,6 +710,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             fin = LV32(sync_a + SY_FIN);
             cp = LV32(sync_a + SY_C);
             LV32(sync_a + SY_HTICK) = k + 1u;  // (behind the reads of the buffer: the chain may reuse it)
+#ifdef ROWS_DIAG_LAG
+            lag_d3 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
+#endif
             {   // the window top-ups this tick's steps call for, first of all (the chain lands them at the end of its next tick:
                 // what has not arrived by then is lost)
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
@@ -693,8 +720,20 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
+#ifdef ROWS_DIAG_LAG
+            {
+                const uint32_t dl = (uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u);
+                lag_sum += dl;
+                lag_n += 1.0;
+                lag_over += dl > 2500u ? 1.0 : 0.0;
+                lag_max = dl > lag_max ? dl : lag_max;
+            }
+#endif
             const uint32_t pos_i = positions(n, le);
             PF_PH(9);
+            // the slots the reward pipeline reads were loaded by the previous round: everything but this round's request loads
+            if (ROWS_RQ_MAX > 4u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             rewards_a();
             rewards_b(n, le, pos_i);
             if (gen - cp < 240u) {
@@ -717,6 +756,19 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             out.sum_g[r] = sum_g;
             out.n_ep[r] = ep_acc;
             out.n_len[r] = n_len;
+#ifdef ROWS_DIAG_LAG
+            if (out.dbg && out.ep_g && out.ep_cap >= 4) {
+                out.ep_g[r * out.ep_cap + 0] = lag_sum;
+                out.ep_g[r * out.ep_cap + 1] = lag_n;
+                out.ep_g[r * out.ep_cap + 2] = lag_over;
+                out.ep_g[r * out.ep_cap + 3] = (double)lag_max;
+                if (out.ep_cap >= 8) {
+                    out.ep_g[r * out.ep_cap + 4] = lag_d1;
+                    out.ep_g[r * out.ep_cap + 5] = lag_d2;
+                    out.ep_g[r * out.ep_cap + 6] = lag_d3;
+                }
+            }
+#endif
 #ifdef OFFSIM_ROWS_PROF
             if (out.dbg && out.ep_g && out.ep_cap >= 24)
                 for (int k = 0; k < 12; k++) out.ep_g[r * out.ep_cap + 12 + k] = (double)pf_ph[k];
@@ -738,14 +790,30 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         uint32_t v_ht = 0, v_gen = 0;
         uint32_t le = 0;
         if (HELPER) {
-            // One batch of reads: the flag of the helper's request round (it made the requests of the PREVIOUS tick's steps while
-            // this tick ran), the descriptors and digests of that round, and the two counters the next tick needs.  A flag that
-            // is not there yet is rare (the helper is a tick ahead); only then are the reads repeated behind a bounded wait.
-            const uint32_t v_req = LV32(sync_a + SY_REQ);
-            uint32_t dsc = dma_slot(DS_RQD);
-            in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
+            // First what does not depend on the helper's request round -- the later that round is looked at, the more of its loads
+            // have arrived (what has not by then is a top-up lost): the two counters the next tick needs, the initial-state ring.
             v_ht = LV32(sync_a + SY_HTICK);
             v_gen = LV32(sync_a + SY_GEN);
+            if (!dead) {
+                prefetch_step();
+                // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
+                const uint32_t want_h = tick_k;
+                if (__ballot(v_ht < want_h) != 0ull && !spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
+                    status = OFFSIM_ST_PROTOCOL;
+                    dead = 1u;
+                }
+                if (!dead) {
+                    gen = v_gen;
+                    need_draws(136u, 0u);
+                }
+            }
+            PF_PH(7);
+            // One batch of reads: the flag of the helper's request round (it made the requests of the PREVIOUS tick's steps while
+            // this tick ran), the descriptors and digests of that round.  A flag that is not there yet is rare (the helper is a
+            // tick ahead); only then are the reads repeated behind a bounded wait.
+            const uint32_t v_req = LV32(sync_a + SY_REQ);
+            uint32_t dsc = dma_slot(DS_RQD);
+            in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
             if (tick_k >= 1u) {
                 const uint32_t want_r = tick_k;
                 if (__ballot(v_req < want_r) != 0ull) {
@@ -754,7 +822,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                         dead = 1u;
                     }
                     dsc = dma_slot(DS_RQD);
-                    in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
+                    in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
                 }
                 rq_p = dsc & 0x1ffffu;
                 rq_s = (dsc >> 17) & 0x3ffu;
@@ -763,7 +831,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
             le = LV32(log_a + li4);
-            in_a = LV128(dma_a + DS_RQA * 256u + lane * 16u), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
+            in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
         }
         PF_PH(0);
         // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
@@ -775,23 +843,17 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             land_ld = LV32(land_a + rq_s * 4u);
             land_have = rows_held(h0, h1);
         }
-        if (HELPER) {
-            // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
-            // order); ahead of the landing, whose reads are still in flight -- a request made from the older end of a window
-            // lands only as far as it still fits
-            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
-            LV32(sync_a + SY_C) = c;
-            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
-            LV32(sync_a + SY_TICK) = tick_k + 1u;
-        }
         PF_PH(1);
         {
             // A request lands where it was aimed at -- the window's end; one that a direct read has overtaken meanwhile is dropped
             // (the state is topped up again when it is next left).  Of what was asked for, the groups of four that have arrived
             // land as far as the window has room; the other stores go to a scratch word.
             const bool hit = rq_n != 0u && rq_p == land_ld;
+            n_req += rq_n != 0u;
+            n_miss += rq_n != 0u && !hit;
             const bool got_a = in_a.x != ROWS_NOT_LANDED && in_a.y != ROWS_NOT_LANDED && in_a.z != ROWS_NOT_LANDED && in_a.w != ROWS_NOT_LANDED;
             uint32_t k = !hit ? 0u : !got_a ? 0u : rq_n < 4u ? rq_n : 4u;
+            n_late += hit && !got_a;
             if (ROWS_RQ_MAX > 4u) {
                 const bool got_b = in_b.x != ROWS_NOT_LANDED && in_b.y != ROWS_NOT_LANDED && in_b.z != ROWS_NOT_LANDED && in_b.w != ROWS_NOT_LANDED;
                 k = (k == 4u && got_b) ? rq_n : k;
@@ -813,25 +875,23 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (k) LV32(land_a + rq_s * 4u) = land_ld + k;
             rq_n = 0;
         }
+        if (HELPER) {
+            // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
+            // order) -- BEHIND the landing: the helper aims its next requests at the windows' ends as it finds them, and a
+            // request aimed at an end that is about to move is a request lost
+            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
+            LV32(sync_a + SY_C) = c;
+            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
+#ifdef ROWS_DIAG_LAG
+            LV32(sync_a + 60u) = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+            LV32(sync_a + SY_TICK) = tick_k + 1u;
+        }
         PF_PH(2);
         if (HELPER) {
             steps += n;
             tick_k++;
             log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
-            if (!dead) {
-                prefetch_step();
-                // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
-                const uint32_t want_h = tick_k - 1u;
-                if (__ballot(v_ht < want_h) != 0ull && !spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
-                    status = OFFSIM_ST_PROTOCOL;
-                    dead = 1u;
-                }
-                if (!dead) {
-                    gen = v_gen;
-                    need_draws(136u, 0u);
-                }
-            }
-            PF_PH(7);
         } else {
             const uint32_t pos_i = positions(n, le);
             request(li < n, le & 0x3ffu, rq_s, rq_p, rq_n);
@@ -1100,6 +1160,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
         n_len++;
     }
+    // (diagnostics: top-ups made, aimed at a window end that had moved, not arrived in time -- summed over the row's lanes)
+    if (out.dbg) {
+        for (int m = 1; m < 16; m <<= 1) {
+            n_req += __shfl_xor(n_req, m);
+            n_miss += __shfl_xor(n_miss, m);
+            n_late += __shfl_xor(n_late, m);
+        }
+    }
     // ---- write the env state back ----
     if (r < (int64_t)ro.R) {
         for (uint32_t s = li; s < n_slots; s += 16u) {  // cursor = the position behind the window minus the entries it holds
@@ -1136,8 +1204,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
 #else
             if (out.dbg) {
-                out.dbg[4 * r + 0] = n_dry;
-                out.dbg[4 * r + 1] = n_tie;
+                out.dbg[4 * r + 0] = (int64_t)n_dry | ((int64_t)n_req << 32);
+                out.dbg[4 * r + 1] = (int64_t)n_tie | ((int64_t)n_late << 16) | ((int64_t)n_miss << 40);
                 out.dbg[4 * r + 2] = (int64_t)pf_c1;
                 out.dbg[4 * r + 3] = (int64_t)pf_r1;
             }

@@ -309,6 +309,48 @@ def main():
         np.savez_compressed(os.path.join(OUT, nm + ".npz"), **out)
         print(f"{nm:28s} N={len(inp['z']):6d}")
 
+    # ---- 11b. learner drivers, the rest of their arguments (psrs.py:119-239): callable alpha / epsilon schedules (:128-135), Q_init = None
+    # (:138-139: every first visit is a tie between maxima, which agents/tabular.py:4-5 breaks with np.random.choice, i.e. the global
+    # MT19937 stream: seeded here, and the stream's continuation recorded), save_Q (:172-173), and the other tabular behaviour policies
+    # (greedy_policy, soft_greedy_policy: agents/tabular.py:11-22).  The schedules are restated in tests/test_gpu_round3.py.
+    sched_alpha = lambda ep: 0.5 / (1.0 + 0.1 * ep)
+    sched_eps = lambda ep: max(0.05, 0.9 ** ep)
+    inp = iid2k
+    out = {("in_" + k): v for k, v in inp.items()}
+    out["pi"], out["gamma"] = pi25, np.float64(0.9)
+    h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+    g = np.random.default_rng(77)
+    Qi = g.standard_normal((h.env.nS, 5)) * 0.1
+    out["Q_init"] = Qi
+    out["seeds"] = np.array([0, 3], np.int64)
+
+    def run(tag, s, np_seed, fn):
+        np.random.seed(np_seed)
+        h.env.reset_sampler(seed=s)
+        h.clear()
+        Q, info = fn()
+        out[f"s{s}_{tag}_Q"], out[f"s{s}_{tag}_Gs"] = Q, info["Gs"]
+        if "TD_errors" in info:
+            out[f"s{s}_{tag}_td"] = info["TD_errors"]
+        out[f"s{s}_{tag}_rows"] = np.array([r for r in h.rows if r >= 0], np.int64)
+        out[f"s{s}_{tag}_p"] = np.array([m[5] for m in info["memory"]])       # behaviour distribution of every step
+        out[f"s{s}_{tag}_after"] = np.random.random(3)                       # where the global stream stands afterwards
+        out[f"s{s}_{tag}_np_seed"] = np.int64(np_seed)
+        return info
+
+    for s in (0, 3):
+        run("sched", s, 7, lambda: ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.epsilon_greedy_policy, 0.9, alpha=sched_alpha, epsilon=sched_eps, Q_init=Qi))
+        run("ties", s, 1234, lambda: ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.epsilon_greedy_policy, 0.9, alpha=0.1, epsilon=0.3, Q_init=None))
+        run("ties_sched", s, 99, lambda: ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.epsilon_greedy_policy, 0.9, alpha=sched_alpha, epsilon=sched_eps, Q_init=None))
+        run("greedy", s, 3, lambda: ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.greedy_policy, 0.9, alpha=0.1, Q_init=None))
+        run("soft", s, 4, lambda: ref_psrs.qlearn_psrs(h.env, 10 ** 9, ref_tab.soft_greedy_policy, 0.9, alpha=0.1, Q_init=None))
+        info = run("saveq", s, 5, lambda: ref_psrs.qlearn_psrs(h.env, 12, ref_tab.epsilon_greedy_policy, 0.9, alpha=0.1, epsilon=0.2, Q_init=None, save_Q=1))
+        out[f"s{s}_saveq_Qs"] = info["Qs"]
+        info = run("es_sched", s, 6, lambda: ref_psrs.expSARSA_psrs(h.env, 12, pi25, 0.9, alpha=sched_alpha, save_Q=1))
+        out[f"s{s}_es_sched_Qs"] = info["Qs"]
+    np.savez_compressed(os.path.join(OUT, "td2_iid_2k.npz"), **out)
+    print(f"{'td2_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's0_{t}_rows']) for t in ('sched', 'ties', 'ties_sched', 'greedy', 'soft', 'saveq', 'es_sched')]}")
+
     # ---- 12. QueueEvaluator_impl (queue_evaluator.py:90-131): (z, a)-keyed queues, no rejection.  The module imports gym at
     # the top, so only the class (numpy + itertools) is compiled from the reference file, unmodified, in memory.
     import ast

@@ -42,12 +42,27 @@ def test_library_loads_without_gpu_and_reports_errors():
     assert lib.offsim_group_scratch_bytes(10_000_000, 163) > 4 * 163 * 4883
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of every struct of include/offsim.h as gcc lays them out, against the ctypes mirrors in _lib.py."""
+    import subprocess
     from rl_offline_simulation_amd import _lib
-    assert ctypes.sizeof(_lib.Table) == 8 + 4 * 4 + 7 * 8 + 8 + 2 * 8 + 2 * 8  # ... + max_seg, min_seg
-    assert ctypes.sizeof(_lib.Rollouts) == 8 + 4 * 8 + 8 + 8 + 8 + 8
-    assert ctypes.sizeof(_lib.EvalMCOut) == 13 * 8
-    assert ctypes.sizeof(_lib.TD) == 8 + 8 + 8 + 8 + 8 + 8 + 8 and ctypes.sizeof(_lib.Streams) == 4 * 8
+    pairs = {"offsim_table": _lib.Table, "offsim_rollouts": _lib.Rollouts, "offsim_evalmc_out": _lib.EvalMCOut, "offsim_td": _lib.TD,
+             "offsim_streams": _lib.Streams, "offsim_column": _lib.Column}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "offsim.h"', "int main(void) {"]
+    for c_name, cls in pairs.items():
+        lines.append(f'  printf("{c_name} %zu\\n", sizeof({c_name}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf("{c_name}.{f} %zu\\n", offsetof({c_name}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for c_name, cls in pairs.items():
+        assert int(got[c_name]) == ctypes.sizeof(cls), c_name
+        for f, _ in cls._fields_:
+            assert int(got[f"{c_name}.{f}"]) == getattr(cls, f).offset, (c_name, f)
 
 
 def test_no_cpu_fallback():

@@ -406,7 +406,7 @@ def test_row_packed_scan_matches_the_window_kernel_at_scale(gpu):
             assert torch.equal(oa[k], ob[k]), (R, mode, k)
         assert torch.equal(a.state.cursor, b.state.cursor) and torch.equal(a.state.rng, b.state.rng)
         dbg = oa["dbg"].cpu().numpy()
-        assert (dbg[:, 0] + dbg[:, 1]).sum() < 0.05 * oa["steps"].sum().item()  # exact-path events stay rare
+        assert ((dbg[:, 0] & 0xffffffff) + (dbg[:, 1] & 0xffff)).sum() < 0.05 * oa["steps"].sum().item()  # exact-path events stay rare
 
 
 # ---------------------------------------------------------------------------------------------------

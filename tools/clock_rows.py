@@ -14,10 +14,23 @@ env = BatchedPSRS(table, R)
 for rep in range(2):
     env.reset_sampler(list(range(R)), policy=pi)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record(); o = env.eval_mc(pi, 0.99, dbg=True); t1.record(); torch.cuda.synchronize()
-d = o["dbg"].cpu().numpy()[::4].astype(float)  # one row per chain wavefront
+    t0.record(); o = env.eval_mc(pi, 0.99, dbg=True, ep_cap=8 if os.environ.get("ROWS_DIAG_LAG") else 0); t1.record(); torch.cuda.synchronize()
+raw = o["dbg"].cpu().numpy()
+n_dry, n_req = (raw[:, 0] & 0xffffffff).astype(float), (raw[:, 0] >> 32).astype(float)
+n_tie, n_late, n_miss = (raw[:, 1] & 0xffff).astype(float), ((raw[:, 1] >> 16) & 0xffffff).astype(float), (raw[:, 1] >> 40).astype(float)
+d = raw[::4].astype(float)  # one row per chain wavefront
 it = o["steps"].cpu().numpy().astype(float).max()
 cyc, rt = d[:, 2], d[:, 3]
 print(f"kernel {t0.elapsed_time(t1):.1f} ms; chain wavefronts: {cyc.mean() / it:.1f} cycles per iteration (mean), clock {(cyc / rt).mean() * 0.1:.3f} GHz, "
-      f"wall of the mean / slowest wavefront {rt.mean() * 1e-5:.1f} / {rt.max() * 1e-5:.1f} ms; dry events per row {o['dbg'].cpu().numpy()[:, 0].mean():.0f}, ties {o['dbg'].cpu().numpy()[:, 1].mean():.1f}")
+      f"wall of the mean / slowest wavefront {rt.mean() * 1e-5:.1f} / {rt.max() * 1e-5:.1f} ms; dry events per row {n_dry.mean():.0f}, ties {n_tie.mean():.1f}")
+dry = n_dry.reshape(-1, 16)
+print("by workgroup % 8, per row: top-ups", np.round([n_req.reshape(-1, 16)[b::8].mean() for b in range(8)], 0), " not arrived in time", np.round([n_late.reshape(-1, 16)[b::8].mean() for b in range(8)], 0),
+      " window end had moved", np.round([n_miss.reshape(-1, 16)[b::8].mean() for b in range(8)], 0))
+print("by workgroup % 8: dry events per row", np.round([dry[b::8].mean() for b in range(8)], 0), " cycles per iteration", np.round([cyc.reshape(-1, 4)[b::8].mean() / it for b in range(8)], 1))
 print("by workgroup % 8: wall ms", np.round([rt.reshape(-1, 4)[b::8].mean() * 1e-5 for b in range(8)], 1), " clock GHz", np.round([(cyc / rt).reshape(-1, 4)[b::8].mean() * 0.1 for b in range(8)], 3))
+if os.environ.get("ROWS_DIAG_LAG"):  # library built with -DROWS_DIAG_LAG: cycles from the chain's publishing a tick to the helper's having issued its requests
+    g = o["ep_g"].cpu().numpy()[::4].reshape(-1, 4, 8)
+    for par in (0, 1):
+        x = g[par::2].reshape(-1, 8)
+        print(f"workgroups of parity {par}: tick -> requests issued: mean {x[:, 0].sum() / x[:, 1].sum():.0f} cycles, over 2500 in {x[:, 2].sum() / x[:, 1].sum() * 100:.2f} % of the ticks, max {x[:, 3].max():.0f};"
+              f" tick seen at {x[:, 4].sum() / x[:, 1].sum():.0f}, request areas free at {x[:, 5].sum() / x[:, 1].sum():.0f}, log read at {x[:, 6].sum() / x[:, 1].sum():.0f}")

@@ -42,3 +42,7 @@ order = np.argsort(tot)
 st16 = steps.reshape(-1, 16)
 for w in list(order[-5:]) + list(order[:3]):
     print(f"  block {w:3d}: total {tot[w] / tot.mean():.4f}  fast {d[w, 0] / it:.1f} slow {d[w, 1] / it:.1f} tick {d[w, 2] / it:.1f}  nslow {(d[w, 3] & 0xffffffff)}  steps of wave 0 {st16[w, :4].astype(int).tolist()}")
+ga = o["ep_g"].cpu().numpy()[::16]
+for par in (0, 1):
+    phs = ga[par::2].mean(axis=0)
+    print(f"parity {par}: chain tick phases", {n: int(v / (it / 16)) for n, v in zip(names, phs[:8]) if n != "-"}, " helper", {v: int(phs[12 + k] / (it / 16)) for k, v in hn.items()})
