@@ -632,6 +632,52 @@ __global__ void __launch_bounds__(256) k_step_batch(offsim_table t, offsim_rollo
 // ---- eval_mc: the whole evalMC_psrs loop (psrs.py:241-271) on device, cursors in LDS ----
 // TD = true adds the tabular learner of qlearn_psrs / expSARSA_psrs (psrs.py:119-239) to the loop: the rollout's
 // Q[n_slots,nA] lives in LDS and is updated after every accepted step, in step order.
+// ---- NumPy's global (legacy) MT19937 stream on the device, for np.random.choice among tied maxima (offsim4rl/agents/tabular.py:4-5).
+// The state lives in LDS: 624 words + the position, as np.random.get_state() returns them.  Every lane runs the same code on the same
+// values; the regeneration of the 624 words is spread over the wavefront's lanes.
+__device__ __forceinline__ void mt_twist(volatile uint32_t *mt, int lane) {
+    // new[k] = new-or-old[(k + 397) % 624] ^ twist(old[k], old-or-new[(k + 1) % 624]); in chunks of 64 consecutive k every lane reads
+    // before any lane writes (one instruction each), later chunks see the words earlier chunks wrote -- the order the scalar code has
+    for (int base = 0; base < 624; base += 64) {
+        const int k = base + lane;
+        uint32_t v = 0;
+        if (k < 624) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            v = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (k < 624) mt[k] = v;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+__device__ __forceinline__ uint32_t mt_next(volatile uint32_t *mt, uint32_t &pos, int lane) {
+    if (pos >= 624u) {
+        mt_twist(mt, lane);
+        pos = 0u;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+// RandomState.randint(0, rng + 1) (numpy/random/_bounded_integers: masked rejection on 32-bit words; nothing is drawn for rng = 0)
+__device__ __forceinline__ uint32_t mt_bounded(volatile uint32_t *mt, uint32_t &pos, int lane, uint32_t rng) {
+    if (rng == 0u) return 0u;
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+        v = mt_next(mt, pos, lane) & mask;
+    } while (v > rng);
+    return v;
+}
+
 template <typename PL, typename PROB, bool TD>
 __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollouts ro, const PROB *__restrict__ pi,
                                                  int reject_mode, double gamma, const double *__restrict__ gamma_pow,
@@ -648,6 +694,8 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     uint32_t *cur_lds = seg_lds + (n_slots + 1) + (size_t)wave * n_slots;
     // TD with an epsilon-greedy behaviour policy: this rollout's action distribution in its current state, rebuilt from its Q row before every step
     double *beh_lds = (double *)(((uintptr_t)(seg_lds + (n_slots + 1) + (size_t)waves * n_slots) + 7) & ~(uintptr_t)7) + (size_t)wave * nA;
+    // TD: this rollout's copy of the tie-breaking MT19937 stream (624 words; the position is kept in a register)
+    volatile uint32_t *mt_lds = (volatile uint32_t *)(((double *)(((uintptr_t)(seg_lds + (n_slots + 1) + (size_t)waves * n_slots) + 7) & ~(uintptr_t)7)) + (size_t)waves * nA) + (size_t)wave * 624;
     for (int i = threadIdx.x; i < n_slots * nA; i += blockDim.x) pi_lds[i] = pi[i];
     for (int i = threadIdx.x; i <= n_slots; i += blockDim.x) seg_lds[i] = t.seg_off[i];
     __syncthreads();
@@ -655,8 +703,14 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     if (r >= ro.R) return;
     uint32_t *cur_glb = ro.cursor + (int64_t)r * n_slots;
     for (int s = lane; s < n_slots; s += WAVE) cur_lds[s] = cur_glb[s];
-    if (TD)
+    uint32_t mt_pos = 624u;
+    if (TD) {
         for (int i = lane; i < n_slots * nA; i += WAVE) q_lds[i] = td.q[(int64_t)r * n_slots * nA + i];
+        if (td.tie_mt) {
+            for (int i = lane; i < 624; i += WAVE) mt_lds[i] = td.tie_mt[(int64_t)r * 625 + i];
+            mt_pos = td.tie_mt[(int64_t)r * 625 + 624];
+        }
+    }
 
     WaveRng rng;
     U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
@@ -689,15 +743,39 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
         while (!done) {
             const double gp = discount_at(gamma_pow, (uint64_t)n_gamma_pow, gamma, (uint64_t)tt);  // issued ahead of the step
             const PROB *p_step = pi_lds + (size_t)slot * nA;
-            if (TD && td.behaviour == OFFSIM_BEHAVIOUR_EPS_GREEDY) {
-                // epsilon_greedy_policy(Q[[S]], epsilon) (offsim4rl/agents/tabular.py:24-32): epsilon / nA everywhere, 1 - epsilon + epsilon / nA
-                // at the maximum of the Q row (the first one: the reference breaks ties with the global NumPy stream)
+            if (TD && td.behaviour != OFFSIM_BEHAVIOUR_FIXED) {
+                // the learner's own behaviour policy on its Q row (offsim4rl/agents/tabular.py), rebuilt in LDS before every step
                 const double *qs = q_lds + (size_t)slot * nA;
-                int best = 0;
-                for (int k = 1; k < nA; k++) best = qs[k] > qs[best] ? k : best;
-                const double lo = td.epsilon / (double)nA, hi = 1.0 - td.epsilon + lo;
+                double mx = qs[0];
+                for (int k = 1; k < nA; k++) mx = qs[k] > mx ? qs[k] : mx;
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                for (int k = lane; k < nA; k += WAVE) beh_lds[k] = k == best ? hi : lo;
+                if (td.behaviour == OFFSIM_BEHAVIOUR_EPS_GREEDY) {
+                    // epsilon_greedy_policy (tabular.py:24-32; epsilon = 0: greedy_policy, :11-16): epsilon / nA everywhere and
+                    // 1 - epsilon + epsilon / nA at _random_argmax -- np.random.choice(np.where(x == np.max(x))[0]), tabular.py:4-5:
+                    // one bounded integer from the tie stream when several actions hold the maximum, none otherwise
+                    int n_max = 0;
+                    for (int k = 0; k < nA; k++) n_max += qs[k] == mx ? 1 : 0;
+                    uint32_t pick = 0;
+                    if (n_max > 1 && td.tie_mt) pick = mt_bounded(mt_lds, mt_pos, lane, (uint32_t)n_max - 1u);
+                    int best = 0, seen = 0;
+                    for (int k = 0; k < nA; k++) {
+                        if (qs[k] == mx) {
+                            if ((uint32_t)seen == pick) best = k;
+                            seen++;
+                        }
+                    }
+                    const double eps = td.epsilon_ep ? td.epsilon_ep[ep < td.n_sched ? ep : td.n_sched - 1] : td.epsilon;
+                    const double lo = eps / (double)nA, hi = 1.0 - eps + lo;
+                    for (int k = lane; k < nA; k += WAVE) beh_lds[k] = k == best ? hi : lo;
+                    if (lane == 0 && td.beh_arg && steps < td.td_cap) td.beh_arg[(int64_t)r * td.td_cap + steps] = best;
+                } else {
+                    // soft_greedy_policy (tabular.py:18-22): uniform over np.isclose(Q[s], max) (rtol 1e-5, atol 1e-8)
+                    const double tol = 1e-8 + 1e-5 * fabs(mx);
+                    int n_close = 0;
+                    for (int k = 0; k < nA; k++) n_close += fabs(qs[k] - mx) <= tol ? 1 : 0;
+                    const double w = 1.0 / (double)n_close;
+                    for (int k = lane; k < nA; k += WAVE) beh_lds[k] = fabs(qs[k] - mx) <= tol ? w : 0.0;
+                }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 p_step = (const PROB *)beh_lds;
             }
@@ -727,8 +805,14 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
                 }
                 const double td_err = s.r + gamma * nxt - q_sa;
                 if (lane == 0 && td.td_err && steps < td.td_cap) td.td_err[(int64_t)r * td.td_cap + steps] = td_err;
+                const double alpha = td.alpha_ep ? td.alpha_ep[ep < td.n_sched ? ep : td.n_sched - 1] : td.alpha;  // alpha(episode), psrs.py:168
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                q_lds[slot * nA + A] = q_sa + td.alpha * td_err;
+                q_lds[slot * nA + A] = q_sa + alpha * td_err;
+                if (td.q_snap && steps % td.snap_stride == 0 && steps / td.snap_stride < td.snap_cap) {  // save_Q (psrs.py:172-173)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    double *dst = td.q_snap + ((int64_t)r * td.snap_cap + steps / td.snap_stride) * n_slots * nA;
+                    for (int i = lane; i < n_slots * nA; i += WAVE) dst[i] = q_lds[i];
+                }
             }
             G = G + gp * s.r;  // :262 (no FMA contraction: built with -ffp-contract=off)
             tt++;
@@ -752,8 +836,13 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     // write back the env state so that a later call continues where this one stopped
     __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int s = lane; s < n_slots; s += WAVE) cur_glb[s] = cur_lds[s];
-    if (TD)
+    if (TD) {
         for (int i = lane; i < n_slots * nA; i += WAVE) td.q[(int64_t)r * n_slots * nA + i] = q_lds[i];
+        if (td.tie_mt) {
+            for (int i = lane; i < 624; i += WAVE) td.tie_mt[(int64_t)r * 625 + i] = mt_lds[i];
+            if (lane == 0) td.tie_mt[(int64_t)r * 625 + 624] = mt_pos;
+        }
+    }
     if (lane == 0) {
         ro.init_cursor[r] = ic;
         ro.cur_slot[r] = slot;
@@ -773,7 +862,7 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
 
 static size_t evalmc_lds_bytes(int waves, int n_slots, int nA, size_t prob_bytes, bool td = false) {
     return (size_t)waves * (WAVE + 1) * sizeof(Jump) + (td ? (size_t)waves * n_slots * nA * 8 : 0) + (size_t)n_slots * nA * prob_bytes +
-           (size_t)(n_slots + 1) * 4 + (size_t)waves * n_slots * 4 + (td ? 8 + (size_t)waves * nA * 8 : 0);
+           (size_t)(n_slots + 1) * 4 + (size_t)waves * n_slots * 4 + (td ? 8 + (size_t)waves * nA * 8 + (size_t)waves * 624 * 4 : 0);
 }
 
 static int check_table(const offsim_table *t) {
@@ -978,7 +1067,10 @@ extern "C" int offsim_eval_td(const offsim_table *t, offsim_rollouts *ro, const 
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_td: required output is NULL%s");
     if ((td->mode != OFFSIM_TD_QLEARN && td->mode != OFFSIM_TD_EXPSARSA) || !td->q) return fail(OFFSIM_EINVAL, "eval_td: bad td mode or NULL q%s");
-    if (td->behaviour != OFFSIM_BEHAVIOUR_FIXED && td->behaviour != OFFSIM_BEHAVIOUR_EPS_GREEDY) return fail(OFFSIM_EINVAL, "eval_td: bad behaviour%s");
+    if (td->behaviour != OFFSIM_BEHAVIOUR_FIXED && td->behaviour != OFFSIM_BEHAVIOUR_EPS_GREEDY && td->behaviour != OFFSIM_BEHAVIOUR_SOFT_GREEDY)
+        return fail(OFFSIM_EINVAL, "eval_td: bad behaviour%s");
+    if ((td->alpha_ep || td->epsilon_ep) && td->n_sched <= 0) return fail(OFFSIM_EINVAL, "eval_td: schedules need n_sched > 0%s");
+    if (td->q_snap && (td->snap_stride <= 0 || td->snap_cap < 0)) return fail(OFFSIM_EINVAL, "eval_td: bad snapshot stride / capacity%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_td: gamma_pow is NULL%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -73,7 +73,8 @@ class BatchedPSRS:
     def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None):
         """`policy` (optional, [n_slots,nA] f64): the tabular policy the following eval_mc calls will evaluate.  It changes no
         result; it lets the sampler reset write the queue orders as the candidate streams the row-packed scan reads
-        sequentially (offsim_shuffle_queues_keys: digest + 16-bit local row per queue position) instead of as permutations."""
+        sequentially (offsim_shuffle_queues_keys: digest + 16-bit local row per queue position) instead of as permutations.
+        (step / step_single / eval_td / the generic eval_mc need permutations and rebuild them from the streams on first use.)"""
         t, dev = self.table, self.table.device
         sd = seeds_tensor(seeds, dev)
         assert sd.numel() == self.R, "one seed per rollout"
@@ -184,6 +185,14 @@ class BatchedPSRS:
         """Replace only the rejection streams (env.rejection_sampling_rng = default_rng(seed), psrs.py:20)."""
         seed_streams(seeds_tensor(seeds, self.table.device), self.state.rng)
 
+    def _orders_for_generic(self):
+        """The kernels that take any p_new per step (step, step_single, eval_td, the generic eval_mc) walk the queues through
+        permutations.  After reset_sampler(policy=...) the orders exist only as candidate streams: the permutations are rebuilt
+        from the streams' local rows here, once (4 * R * N bytes) -- never left as table order by default."""
+        if self.state.perm is None and self._perm_lazy == "streams":
+            self.state.set_orders(self.perm.contiguous(), self.table.N, self.state.init_perm, self.state.init_stride)
+            self._perm_buf = self.state.perm
+
     # -- PSRS.reset (psrs.py:32-37) --
     def reset(self, mask=None):
         m = None if mask is None else mask.to(torch.uint8).contiguous()
@@ -193,6 +202,7 @@ class BatchedPSRS:
     # -- PSRS.step (psrs.py:39-51) --
     def step(self, p_new, advance=True, reject_mode=None):
         """p_new: [R,nA] tensor/array.  Returns device tensors (row, status, popped)."""
+        self._orders_for_generic()
         t = self.table
         if not isinstance(p_new, torch.Tensor):
             p_new = torch.from_numpy(np.ascontiguousarray(p_new))
@@ -207,6 +217,7 @@ class BatchedPSRS:
         """R = 1 convenience for the drop-in classes: one launch per call.  The kernel reads p_new from, and writes
         (row, status, popped) to, pinned host memory mapped into the device's address space, so that no copy is enqueued:
         the call is launch + stream synchronise.  Returns host ints (row, status, popped)."""
+        self._orders_for_generic()
         t = self.table
         p_new = np.asarray(p_new)
         mode = _prob_mode(t, p_new.dtype)
@@ -286,8 +297,7 @@ class BatchedPSRS:
                                                  gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys)
         else:
-            if self.state.perm is None and self._perm_lazy == "streams":
-                self.state.set_orders(self.perm, t.N, self.state.init_perm, self.state.init_stride)  # (materialise the permutations)
+            self._orders_for_generic()  # (materialise the permutations)
             L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
                                             L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp)
@@ -295,11 +305,14 @@ class BatchedPSRS:
 
     # -- qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with a Q-independent behaviour policy, all rollouts in one launch --
     def eval_td(self, pi_slots, gamma, mode, alpha, q_slots=None, n_episodes=None, ep_cap=0, trace_cap=0, n_gamma_pow=4096,
-                behaviour=L.BEHAVIOUR_FIXED, epsilon=0.0):
+                behaviour=L.BEHAVIOUR_FIXED, epsilon=0.0, alpha_ep=None, epsilon_ep=None, snap_cap=0, snap_stride=1, tie_mt=None):
         """mode: _lib.TD_QLEARN | _lib.TD_EXPSARSA.  q_slots [R,n_slots,nA] f64 (Q_init; zeros if None) is updated in place
         and returned as out["q"]; out["td_err"] [R,trace_cap] holds the TD errors in step order.
-        behaviour = _lib.BEHAVIOUR_EPS_GREEDY: every rollout acts epsilon-greedily on its own Q table (the learner-in-the-loop
-        case of psrs.py:158); pi_slots is then only the target policy of expected SARSA."""
+        behaviour = _lib.BEHAVIOUR_EPS_GREEDY / BEHAVIOUR_SOFT_GREEDY: every rollout acts on its own Q table (the learner-in-the-loop
+        case of psrs.py:158); pi_slots is then only the target policy of expected SARSA.  alpha_ep / epsilon_ep: per-episode
+        schedules (psrs.py:128-135); snap_cap > 0: out["q_snap"] [R,snap_cap,n_slots,nA] = Q after every snap_stride-th step
+        (save_Q); tie_mt [R,625] int32/uint32: NumPy's MT19937 state per rollout for ties between maxima (advanced in place)."""
+        self._orders_for_generic()
         t, dev, R = self.table, self.table.device, self.R
         pi_d = torch.as_tensor(np.ascontiguousarray(pi_slots), dtype=torch.float64).to(dev).reshape(t.n_slots, t.nA).contiguous()
         if n_episodes is None:
@@ -315,16 +328,30 @@ class BatchedPSRS:
             o["trace_row"] = torch.full((R, trace_cap), -1, dtype=torch.int32, device=dev)
             o["trace_pop"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
             o["td_err"] = torch.zeros((R, trace_cap), dtype=torch.float64, device=dev)
+            if behaviour == L.BEHAVIOUR_EPS_GREEDY:
+                o["beh_arg"] = torch.zeros((R, trace_cap), dtype=torch.int32, device=dev)
+        a_ep = None if alpha_ep is None else torch.as_tensor(np.ascontiguousarray(alpha_ep, dtype=np.float64)).to(dev)
+        e_ep = None if epsilon_ep is None else torch.as_tensor(np.ascontiguousarray(epsilon_ep, dtype=np.float64)).to(dev)
+        n_sched = max(a_ep.numel() if a_ep is not None else 0, e_ep.numel() if e_ep is not None else 0)
+        assert all(x is None or x.numel() == n_sched for x in (a_ep, e_ep)), "alpha_ep and epsilon_ep cover the same episodes"
+        if snap_cap:
+            o["q_snap"] = torch.zeros((R, snap_cap, t.n_slots, t.nA), dtype=torch.float64, device=dev)
+        mt = None
+        if tie_mt is not None:
+            mt = torch.as_tensor(np.ascontiguousarray(tie_mt).view(np.int32) if not isinstance(tie_mt, torch.Tensor) else tie_mt)
+            mt = mt.to(device=dev, dtype=torch.int32).reshape(R, 625).contiguous()
+            o["tie_mt"] = mt
         gp = _gamma_pow(gamma, n_gamma_pow, dev, cap=t.N + 2)
         oc = L.EvalMCOut(sum_g=L.ptr(o["sum_g"]), n_ep=L.ptr(o["n_ep"]), steps=L.ptr(o["steps"]), cand=L.ptr(o["cand"]),
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")), ep_len=L.ptr(o.get("ep_len")),
                          ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")), trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
         tdc = L.TD(mode=mode, alpha=float(alpha), q=L.ptr(q), td_err=L.ptr(o.get("td_err")), td_cap=trace_cap, behaviour=int(behaviour),
-                   epsilon=float(epsilon))
+                   epsilon=float(epsilon), alpha_ep=L.ptr(a_ep), epsilon_ep=L.ptr(e_ep), n_sched=n_sched, q_snap=L.ptr(o.get("q_snap")),
+                   snap_cap=snap_cap, snap_stride=max(int(snap_stride), 1), tie_mt=L.ptr(mt), beh_arg=L.ptr(o.get("beh_arg")))
         L.check(L.load().offsim_eval_td(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), self.reject_mode, float(gamma), L.ptr(gp),
                                         gp.numel(), int(n_episodes), C.byref(oc), C.byref(tdc), L.stream_ptr()))
         o["q"] = q
-        o["_keepalive"] = (pi_d, gp)
+        o["_keepalive"] = (pi_d, gp, a_ep, e_ep)
         return o
 
     def scan_variant(self):
@@ -539,45 +566,39 @@ def _all_equal(xs, arr):
 
 
 # ---------------------------------------------------------------------------------------------------
+def _require_device_env(env, what):
+    """The drivers run on the device or not at all: a PSRS of this package whose observations are its latent states (Q / pi are
+    indexed by the observation, psrs.py:158,255) and whose reject rule is built in."""
+    if not isinstance(env, PSRS):
+        raise TypeError(f"{what}: `env` must be the device-backed PSRS of this package (PSRS(...) / PSRS.from_arrays(...)), got {type(env).__name__}")
+    if env._reject_func is not None:
+        raise NotImplementedError(f"{what}: a Python reject hook decides every candidate on the host; drive env.step yourself, or use the built-in "
+                                  "rule (reject_func=None) / the trivial baselines' reject modes")
+    if not env._obs_is_state:
+        raise NotImplementedError(f"{what}: the observations of this PSRS differ from its latent states, but the tabular drivers index their "
+                                  "tables by the observation (psrs.py:158, :255)")
+
+
 def evalMC_psrs(env, n_episodes, pi, gamma):
-    """psrs.py:241-271.  For a device-backed PSRS whose observations are its latent states and whose reject rule is
-    built in, the whole loop runs in one kernel launch; otherwise the reference's host loop drives env.step."""
-    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and isinstance(pi, np.ndarray) and pi.ndim == 2:
-        t = env.table
-        if t.N and pi.shape[0] <= int(t.slot_z.max()):
-            raise IndexError("pi has no row for some latent state")
-        n_ep = int(min(n_episodes, t.N0 + 1))
-        o = env._env.eval_mc(t.policy_slots(pi), gamma, n_ep, ep_cap=max(n_ep, 1))
-        status = int(o["status"].cpu()[0])
-        if status == L.ST_KEYERROR:
-            raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
-        ne, nl = int(o["n_ep"].cpu()[0]), int(o["n_len"].cpu()[0])
-        cs = int(env._env.state.cur_slot.cpu()[0])
-        env.z = t.z_of(cs) if cs >= 0 else env.z
-        if cs < 0:
-            env.s = None
-        return o["ep_g"].cpu().numpy()[0, :ne].copy(), o["ep_len"].cpu().numpy()[0, :nl].astype(np.int64)
-    Gs, lengths = [], []
-    episode, terminate = 0, False
-    while episode < n_episodes and not terminate:
-        G, t = 0, 0
-        S = env.reset(seed=episode)
-        if S is None:
-            break
-        done = False
-        while not done:
-            S_, R, done, info = env.step(pi[S])
-            if S_ is None:
-                terminate = True
-                break
-            S = S_
-            G = G + (gamma ** t) * R
-            t = t + 1
-        lengths.append(t)
-        if done:
-            Gs.append(G)
-            episode += 1
-    return np.array(Gs), np.array(lengths)
+    """psrs.py:241-271: the whole loop -- env.reset(), env.step(pi[S]) until exhaustion, discounted returns -- in one kernel launch."""
+    _require_device_env(env, "evalMC_psrs")
+    pi = np.asarray(pi)
+    if pi.ndim != 2:
+        raise ValueError("evalMC_psrs: pi must be a [nS, nA] table")
+    t = env.table
+    if t.N and pi.shape[0] <= int(t.slot_z.max()):
+        raise IndexError("pi has no row for some latent state")
+    n_ep = int(min(n_episodes, t.N0 + 1))
+    o = env._env.eval_mc(t.policy_slots(pi), gamma, n_ep, ep_cap=max(n_ep, 1))
+    status = int(o["status"].cpu()[0])
+    if status == L.ST_KEYERROR:
+        raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
+    ne, nl = int(o["n_ep"].cpu()[0]), int(o["n_len"].cpu()[0])
+    cs = int(env._env.state.cur_slot.cpu()[0])
+    env.z = t.z_of(cs) if cs >= 0 else env.z
+    if cs < 0:
+        env.s = None
+    return o["ep_g"].cpu().numpy()[0, :ne].copy(), o["ep_len"].cpu().numpy()[0, :nl].astype(np.int64)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -585,73 +606,84 @@ def evalMC_psrs(env, n_episodes, pi, gamma):
 # ---------------------------------------------------------------------------------------------------
 def _q_to_slots(table, Q):
     """Rows of a [nS,nA] table in slot order (NumPy indexing for z = -1), zeros where Q has no row."""
-    out = np.nan_to_num(table.policy_slots(np.asarray(Q, dtype=np.float64)), nan=0.0)
-    return out
+    return np.nan_to_num(table.policy_slots(np.asarray(Q, dtype=np.float64)), nan=0.0)
 
 
 def _slots_to_q(table, q_slots, Q):
-    Q = np.array(Q, dtype=np.float64, copy=True)
+    """q_slots [..., n_slots, nA] back into copies of the [nS,nA] table Q (rows without a slot keep Q's values)."""
+    q_slots = np.asarray(q_slots)
+    out = np.broadcast_to(np.asarray(Q, dtype=np.float64), q_slots.shape[:-2] + np.shape(Q)).copy()
     for s in range(table.n_slots):
         z = table.z_of(s)
-        if -Q.shape[0] <= z < Q.shape[0]:
-            Q[z] = q_slots[s]
-    return Q
+        if -out.shape[-2] <= z < out.shape[-2]:
+            out[..., z, :] = q_slots[..., s, :]
+    return out
 
 
-def _fixed_behaviour(behavior_policy, nA, epsilon):
-    """The behaviour distribution if it does not depend on Q (e.g. epsilon = 1 or a uniform policy), else None."""
-    g = np.random.default_rng(0)
-    outs = [np.asarray(behavior_policy(q, dict(epsilon=epsilon)))[0] for q in (np.zeros((1, nA)), g.standard_normal((1, nA)), -g.random((1, nA)))]
-    return outs[0] if all(np.array_equal(outs[0], o) for o in outs[1:]) else None
-
-
-def _eps_greedy_behaviour(behavior_policy, nA, epsilon):
-    """True if behavior_policy(Q, {'epsilon': e}) is epsilon_greedy_policy of offsim4rl/agents/tabular.py:24-32: e / nA everywhere
-    and 1 - e + e / nA at the maximum of each row (probed on rows without ties)."""
-    if nA < 2:
-        return False
+def _behaviour_kind(behavior_policy, nA):
+    """Which of the reference's tabular behaviour policies (offsim4rl/agents/tabular.py:7-32) `behavior_policy(Q, {'epsilon': e})` is,
+    found by probing it on a few Q rows: ('fixed', dist) for one that ignores Q (uniformly_random_policy), 'eps_greedy', 'greedy',
+    'soft_greedy'.  Anything else cannot run on the device.  (The global NumPy stream, which the greedy policies draw from on ties,
+    is put back as it was.)"""
     g = np.random.default_rng(1)
-    lo, hi = np.ones(1)[0] * epsilon / nA, 1 - epsilon + epsilon / nA
-    state = np.random.get_state()  # the reference's _random_argmax draws from the global stream even without a tie
+    state = np.random.get_state()
     try:
-        for _ in range(4):
-            q = g.permutation(nA).astype(float)[None, :] + g.random((1, nA)) * 0.5
-            want = np.full((1, nA), lo)
-            want[0, int(np.argmax(q[0]))] = hi
-            if not np.array_equal(np.asarray(behavior_policy(q, dict(epsilon=epsilon))), want):
-                return False
-    except Exception:
-        return False
+        call = lambda q, e: np.asarray(behavior_policy(np.asarray(q, dtype=np.float64)[None, :], dict(epsilon=e)), dtype=np.float64)[0]
+        rows = [g.permutation(nA).astype(float) + g.random(nA) * 0.5 for _ in range(3)]
+        outs = {e: [call(q, e) for q in rows] for e in (0.3, 0.7)}
+        if all(np.array_equal(outs[e][0], o) for e in outs for o in outs[e][1:]):
+            if np.array_equal(outs[0.3][0], outs[0.7][0]):
+                return "fixed", outs[0.3][0]
+            raise NotImplementedError("behaviour policy ignores Q but follows epsilon: not one of the reference's tabular policies")
+        if nA < 2:
+            raise NotImplementedError("behaviour policy on a single action")
+
+        def pattern(q, lo, hi):
+            w = np.full(nA, lo)
+            w[int(np.argmax(q))] = hi
+            return w
+        if all(np.array_equal(o, pattern(q, e / nA, 1 - e + e / nA)) for e in outs for q, o in zip(rows, outs[e])):
+            return "eps_greedy", None
+        if all(np.array_equal(o, pattern(q, 0.0, 1.0)) for e in outs for q, o in zip(rows, outs[e])):
+            near = rows[0].copy()
+            near[int(np.argsort(near)[-2])] = near.max() - 1e-9  # two values np.isclose to each other, not equal
+            w = call(near, 0.3)
+            if np.count_nonzero(w) == 2 and np.allclose(w[w > 0], 0.5):
+                return "soft_greedy", None
+            if np.array_equal(w, pattern(near, 0.0, 1.0)):
+                return "greedy", None
+    except NotImplementedError:
+        raise
+    except Exception as ex:
+        raise NotImplementedError(f"behaviour policy could not be probed ({ex!r})") from ex
     finally:
         np.random.set_state(state)
-    return True
+    raise NotImplementedError("behaviour policy is none of the reference's tabular policies (uniformly_random_policy, greedy_policy, soft_greedy_policy, "
+                              "epsilon_greedy_policy: offsim4rl/agents/tabular.py:7-32); only those run on the device")
 
 
-class _ReplayedMemory:
-    """The `memory` list of qlearn_psrs for the device path with an epsilon-greedy learner: the behaviour distribution of
-    every step depends on Q at that step, so the tuples are rebuilt by replaying the TD updates over the accepted rows on first use."""
+def _schedule(x, n_ep):
+    """psrs.py:128-135: a callable alpha / epsilon is evaluated per episode; tabulated for the episodes the log can hold."""
+    return np.array([float(x(e)) for e in range(max(n_ep, 1))], dtype=np.float64) if callable(x) else None
 
-    def __init__(self, env, rows, Q0, gamma, alpha, epsilon):
-        self._args, self._items = (env, rows, Q0, gamma, alpha, epsilon), None
+
+class _StepMemory:
+    """The `memory` list of the drivers: (S, A, R, S', done, p, info) per accepted step, p = the behaviour distribution the learner
+    revealed for that step.  Built on first use (for the Q-dependent policies p is a function of the step's Q row, which is
+    replayed from the TD errors the device returned: Q[S,A] += alpha * td is the device's own update)."""
+
+    def __init__(self, env, rows, p_of_step):
+        self._env, self._rows, self._p_of_step, self._items = env, rows, p_of_step, None
 
     def _build(self):
         if self._items is None:
-            env, rows, Q0, gamma, alpha, epsilon = self._args
-            Q = Q0.copy()
-            nA = Q.shape[1]
-            lo, hi = epsilon / nA, 1 - epsilon + epsilon / nA
-            items = []
-            for r in rows:
-                S, A, R, S_ = int(env._z[r]), env._a_of(r), env._r[r], int(env._zn[r])
-                p = np.full(nA, lo)
-                p[int(np.argmax(Q[S]))] = hi
-                items.append((env._obs[r], A, R, env._next_obs[r], bool(env._done[r]), p, {"z": S, "a": A, "p": env._p_of(r)}))
-                Q[S, A] = Q[S, A] + alpha * (R + gamma * Q[S_].max() - Q[S, A])
-            self._items = items
+            env, ps = self._env, self._p_of_step()
+            self._items = [(env._obs[r], env._a_of(r), env._r[r], env._next_obs[r], bool(env._done[r]), ps[i],
+                            {"z": int(env._z[r]), "a": env._a_of(r), "p": env._p_of(r)}) for i, r in enumerate(self._rows)]
         return self._items
 
     def __len__(self):
-        return len(self._args[1])
+        return len(self._rows)
 
     def __iter__(self):
         return iter(self._build())
@@ -660,109 +692,99 @@ class _ReplayedMemory:
         return self._build()[i]
 
 
-def _td_device(env, n_episodes, p_rows, gamma, alpha, mode, Q_init, behaviour=L.BEHAVIOUR_FIXED, epsilon=0.0):
+def _td_run(env, what, n_episodes, gamma, alpha, Q_init, save_Q, mode, kind, pi_rows, epsilon):
+    """One launch of offsim_eval_td for a driver call; returns (Q, info) as the reference does."""
+    _require_device_env(env, what)
     t = env.table
     nS, nA = env.nS, env.nA
     Q0 = np.zeros((nS, nA)) if Q_init is None else np.asarray(Q_init).copy().astype(float)
     n_ep = int(min(n_episodes, t.N0 + 1))
-    o = env._env.eval_td(t.policy_slots(p_rows), gamma, mode, alpha, q_slots=_q_to_slots(t, Q0)[None], n_episodes=n_ep,
-                         ep_cap=n_ep + 1, trace_cap=t.N + 1, behaviour=behaviour, epsilon=epsilon)
+    a_tab, e_tab = _schedule(alpha, n_ep), _schedule(epsilon, n_ep)
+    if kind == "greedy":
+        e_tab, epsilon = None, 0.0
+    behaviour = {"fixed": L.BEHAVIOUR_FIXED, "eps_greedy": L.BEHAVIOUR_EPS_GREEDY, "greedy": L.BEHAVIOUR_EPS_GREEDY,
+                 "soft_greedy": L.BEHAVIOUR_SOFT_GREEDY}[kind]
+    ties = behaviour == L.BEHAVIOUR_EPS_GREEDY
+    if a_tab is not None and e_tab is None:
+        e_tab = np.full(len(a_tab), float(epsilon) if not callable(epsilon) else 0.0)
+    if e_tab is not None and a_tab is None:
+        a_tab = np.full(len(e_tab), float(alpha))
+    mt = None
+    if ties:  # _random_argmax draws from NumPy's global stream (agents/tabular.py:4-5): the device continues it, and hands it back
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise NotImplementedError("np.random's global bit generator is not MT19937")
+        mt = np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)])[None, :]
+    cap = t.N + 1
+    o = env._env.eval_td(t.policy_slots(pi_rows), gamma, mode, 0.0 if callable(alpha) else alpha, q_slots=_q_to_slots(t, Q0)[None],
+                         n_episodes=n_ep, ep_cap=n_ep + 1, trace_cap=cap, behaviour=behaviour, epsilon=0.0 if callable(epsilon) else epsilon,
+                         alpha_ep=a_tab, epsilon_ep=e_tab if behaviour == L.BEHAVIOUR_EPS_GREEDY else None,
+                         snap_cap=cap if save_Q else 0, snap_stride=1, tie_mt=mt)
     status = int(o["status"].cpu()[0])
+    if ties:
+        w = o["tie_mt"].cpu().numpy().view(np.uint32)[0]
+        np.random.set_state(("MT19937", w[:624].copy(), int(w[624]), st[3], st[4]))
     if status == L.ST_KEYERROR:
         raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
     ne, steps = int(o["n_ep"].cpu()[0]), int(o["steps"].cpu()[0])
     n_g = ne + (1 if status == L.ST_EXHAUSTED else 0)  # the cut-short episode's return is appended too (psrs.py:177, :232)
     Q = _slots_to_q(t, o["q"].cpu().numpy()[0], Q0)
     rows = o["trace_row"].cpu().numpy()[0, :steps]
-    return Q, o["ep_g"].cpu().numpy()[0, :n_g].copy(), o["td_err"].cpu().numpy()[0, :steps].copy(), rows, Q0
+    td = o["td_err"].cpu().numpy()[0, :steps].copy()
+    Qs = np.array([Q0])
+    if save_Q:  # psrs.py:145,172-173: Q before the first step, then after every step
+        Qs = np.concatenate([Q0[None], _slots_to_q(t, o["q_snap"].cpu().numpy()[0, :steps], Q0)], axis=0)
+    done = env._done[rows] if steps else np.zeros(0, bool)
+    episode = np.concatenate([[0], np.cumsum(done[:-1])]).astype(np.int64) if steps else np.zeros(0, np.int64)  # psrs.py:180: +1 per finished episode
+    eps_of = (lambda i: e_tab[min(int(episode[i]), len(e_tab) - 1)]) if e_tab is not None else (lambda i: float(epsilon))
+    alpha_of = (lambda i: a_tab[min(int(episode[i]), len(a_tab) - 1)]) if a_tab is not None else (lambda i: float(alpha))
 
+    def p_of_step():
+        if kind == "fixed":
+            return [pi_rows[int(env._z[r])] for r in rows]
+        if behaviour == L.BEHAVIOUR_EPS_GREEDY:
+            best = o["beh_arg"].cpu().numpy()[0, :steps]
+            ps = []
+            for i in range(steps):
+                e = eps_of(i)
+                w = np.ones(nA) * e / nA
+                w[int(best[i])] = 1 - e + e / nA
+                ps.append(w)
+            return ps
+        Qr, ps = Q0.copy(), []  # soft greedy: replay Q from the TD errors
+        for i, r in enumerate(rows):
+            S, A = int(env._z[r]), int(env._a[r])
+            w = np.zeros(nA)
+            w[np.where(np.isclose(Qr[S], np.max(Qr[S])))[0]] = 1
+            ps.append(w / w.sum())
+            Qr[S, A] = Qr[S, A] + alpha_of(i) * td[i]
+        return ps
 
-def _memory(env, rows, p_of_state):
-    return [(env._obs[r], env._a_of(r), env._r[r], env._next_obs[r], bool(env._done[r]), p_of_state(int(env._z[r])),
-             {"z": int(env._z[r]), "a": env._a_of(r), "p": env._p_of(r)}) for r in rows]
+    info = {"Gs": o["ep_g"].cpu().numpy()[0, :n_g].copy(), "Qs": Qs, "memory": _StepMemory(env, rows, p_of_step)}
+    if mode == L.TD_QLEARN:
+        info["TD_errors"] = td
+    return Q, info
 
 
 def qlearn_psrs(env, n_episodes, behavior_policy, gamma, alpha=0.1, epsilon=1.0, Q_init=None, save_Q=0):
-    """psrs.py:119-185.  On a device-backed PSRS the whole loop -- PSRS steps and Q-learning updates -- is one kernel launch
-    when the behaviour policy is Q-independent (epsilon = 1, uniform, ...) or the reference's epsilon_greedy_policy with a
-    constant epsilon; otherwise the reference's host loop drives env.step."""
-    fixed = None
-    on_device = isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not callable(epsilon) and not save_Q
-    if on_device:
-        fixed = _fixed_behaviour(behavior_policy, env.nA, epsilon)
-    if on_device and fixed is None and _eps_greedy_behaviour(behavior_policy, env.nA, epsilon):
-        # the learner acts epsilon-greedily on the Q table it is learning: p_new is rebuilt from the rollout's Q row (in LDS) before
-        # every step.  Ties between maximal Q values go to the first action (the reference draws among them from np.random).
-        t = env.table
-        p_rows = np.full((max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1), env.nA), 1.0 / env.nA)
-        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, p_rows, gamma, alpha, L.TD_QLEARN, Q_init, L.BEHAVIOUR_EPS_GREEDY, epsilon)
-        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "TD_errors": td, "memory": _ReplayedMemory(env, rows, Q0, gamma, alpha, epsilon)}
-    if fixed is not None:
-        t = env.table
-        p_rows = np.tile(np.asarray(fixed, dtype=np.float64), (max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1), 1))
-        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, p_rows, gamma, alpha, L.TD_QLEARN, Q_init)
-        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "TD_errors": td, "memory": _memory(env, rows, lambda z: fixed)}
-    epsilon_func = epsilon if callable(epsilon) else (lambda episode: epsilon)
-    alpha_func = alpha if callable(alpha) else (lambda episode: alpha)
-    Q = np.zeros((env.nS, env.nA)) if Q_init is None else Q_init.copy().astype(float)
-    Gs, Qs, TD_errors, memory_buffer = [], [Q.copy()], [], []
-    episode, terminate = 0, False
-    while episode < n_episodes and not terminate:
-        G, t = 0, 0
-        S = env.reset(seed=episode)
-        if S is None:
-            break
-        done = False
-        while not done:
-            p = behavior_policy(Q[[S], :], dict(epsilon=epsilon_func(episode)))[0]
-            S_, R, done, info = env.step(p)
-            if S_ is None:
-                terminate = True
-                break
-            A = info["a"]
-            memory_buffer.append((S, A, R, S_, done, p, info))
-            TD_errors.append(R + gamma * Q[S_].max() - Q[S, A])
-            Q[S, A] = Q[S, A] + alpha_func(episode) * (R + gamma * Q[S_].max() - Q[S, A])
-            S = S_
-            G = G + (gamma ** t) * R
-            t = t + 1
-            if save_Q:
-                Qs.append(Q.copy())
-        Gs.append(G)
-        episode += 1
-    return Q, {"Gs": np.array(Gs), "Qs": np.array(Qs), "TD_errors": np.array(TD_errors), "memory": memory_buffer}
+    """psrs.py:119-185: Q-learning inside the simulator, the whole loop -- PSRS steps, the behaviour policy on the learner's own Q, the
+    updates -- in one kernel launch.  `behavior_policy` must be one of the reference's tabular policies (agents/tabular.py:7-32; it is
+    recognised by probing, see _behaviour_kind); alpha and epsilon may be callables of the episode (psrs.py:128-135); ties between
+    maximal Q values are broken with NumPy's global stream exactly as the reference's _random_argmax does, and the stream is left
+    where the reference would leave it; save_Q returns Q after every step (psrs.py:172-173)."""
+    _require_device_env(env, "qlearn_psrs")
+    kind, fixed = _behaviour_kind(behavior_policy, env.nA)
+    t = env.table
+    n_rows = max(env.nS, int(t.slot_z.max()) + 1 if t.N else 1)
+    pi_rows = np.tile(np.asarray(fixed, dtype=np.float64), (n_rows, 1)) if kind == "fixed" else np.full((n_rows, env.nA), 1.0 / env.nA)
+    return _td_run(env, "qlearn_psrs", n_episodes, gamma, alpha, Q_init, save_Q, L.TD_QLEARN, kind, pi_rows, epsilon)
 
 
 def expSARSA_psrs(env, n_episodes, pi, gamma, alpha=0.1, Q_init=None, save_Q=0):
-    """psrs.py:187-239: expected SARSA under a fixed target/behaviour policy pi; one launch on a device-backed PSRS."""
-    if isinstance(env, PSRS) and env._reject_func is None and env._obs_is_state and not callable(alpha) and not save_Q and \
-            isinstance(pi, np.ndarray) and pi.ndim == 2:
-        Q, Gs, td, rows, Q0 = _td_device(env, n_episodes, pi, gamma, alpha, L.TD_EXPSARSA, Q_init)
-        return Q, {"Gs": Gs, "Qs": np.array([Q0]), "memory": _memory(env, rows, lambda z: pi[z])}
-    alpha_func = alpha if callable(alpha) else (lambda episode: alpha)
-    Q = np.zeros((env.nS, env.nA)) if Q_init is None else Q_init.copy().astype(float)
-    Gs, Qs, memory_buffer = [], [Q.copy()], []
-    episode, terminate = 0, False
-    while episode < n_episodes and not terminate:
-        G, t = 0, 0
-        S = env.reset(seed=episode)
-        if S is None:
-            break
-        done = False
-        while not done:
-            p = pi[S]
-            S_, R, done, info = env.step(p)
-            if S_ is None:
-                terminate = True
-                break
-            A = info["a"]
-            memory_buffer.append((S, A, R, S_, done, p, info))
-            Q[S, A] = Q[S, A] + alpha_func(episode) * (R + gamma * (Q[S_] @ pi[S_]) - Q[S, A])
-            S = S_
-            G = G + (gamma ** t) * R
-            t = t + 1
-            if save_Q:
-                Qs.append(Q.copy())
-        Gs.append(G)
-        episode += 1
-    return Q, {"Gs": np.array(Gs), "Qs": np.array(Qs), "memory": memory_buffer}
+    """psrs.py:187-239: expected SARSA under a fixed target / behaviour policy pi, one kernel launch; alpha may be a callable of the
+    episode, save_Q returns Q after every step."""
+    _require_device_env(env, "expSARSA_psrs")
+    pi = np.asarray(pi, dtype=np.float64)
+    if pi.ndim != 2:
+        raise ValueError("expSARSA_psrs: pi must be a [nS, nA] table")
+    return _td_run(env, "expSARSA_psrs", n_episodes, gamma, alpha, Q_init, save_Q, L.TD_EXPSARSA, "fixed", pi, 0.0)

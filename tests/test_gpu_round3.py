@@ -1,0 +1,152 @@
+"""Round-3 GPU tests: the learner drivers' remaining arguments against the reference's outputs (schedules, ties broken with NumPy's
+global stream, save_Q, greedy / soft-greedy behaviour), generic kernels after a keyed sampler reset, the hardware self-test."""
+import numpy as np
+import pytest
+
+from common import load
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda", 0)
+
+
+# the reference's tabular policies (offsim4rl/agents/tabular.py:4-32), restated: what a caller would pass
+def _random_argmax(x):
+    return np.random.choice(np.where(x == np.max(x))[0])
+
+
+def greedy_policy(Q, args):
+    pi = np.zeros_like(Q)
+    for s, a in enumerate([_random_argmax(Q[s]) for s in range(len(Q))]):
+        pi[s, a] = 1
+    return pi
+
+
+def soft_greedy_policy(Q, args):
+    pi = np.zeros_like(Q)
+    for s in range(len(Q)):
+        pi[s, np.where(np.isclose(Q[s], np.max(Q[s])))[0]] = 1
+    return pi / pi.sum(axis=1, keepdims=True)
+
+
+def epsilon_greedy_policy(Q, args):
+    epsilon = args["epsilon"]
+    pi = np.ones_like(Q) * epsilon / (Q.shape[1])
+    for s, a in enumerate([_random_argmax(Q[s]) for s in range(len(Q))]):
+        pi[s, a] = 1 - epsilon + epsilon / (Q.shape[1])
+    return pi
+
+
+sched_alpha = lambda ep: 0.5 / (1.0 + 0.1 * ep)   # (tests/golden/make_golden.py, section 11b)
+sched_eps = lambda ep: max(0.05, 0.9 ** ep)
+
+
+def test_learner_drivers_schedules_ties_snapshots_against_the_reference(gpu):
+    """qlearn_psrs / expSARSA_psrs (psrs.py:119-239) with callable alpha / epsilon, Q_init = None (ties at every first visit, broken
+    by np.random.choice on the global MT19937 stream: agents/tabular.py:4-5), save_Q, greedy_policy and soft_greedy_policy: Q, Gs, TD
+    errors, accepted rows, every step's behaviour distribution and the position of the global stream afterwards equal what the
+    reference produced (tests/golden/td2_iid_2k.npz)."""
+    from rl_offline_simulation_amd.evaluators import PSRS, qlearn_psrs, expSARSA_psrs
+    d = load("td2_iid_2k")
+    env = PSRS.from_arrays(d["in_z"], d["in_a"], d["in_r"], d["in_z_next"], d["in_done"], d["in_p_log"], d["in_t0"], nS=d["Q_init"].shape[0], nA=5)
+    gam, Qi, pi = float(d["gamma"]), d["Q_init"], d["pi"]
+    runs = {
+        "sched": lambda: qlearn_psrs(env, 10 ** 9, epsilon_greedy_policy, gam, alpha=sched_alpha, epsilon=sched_eps, Q_init=Qi),
+        "ties": lambda: qlearn_psrs(env, 10 ** 9, epsilon_greedy_policy, gam, alpha=0.1, epsilon=0.3, Q_init=None),
+        "ties_sched": lambda: qlearn_psrs(env, 10 ** 9, epsilon_greedy_policy, gam, alpha=sched_alpha, epsilon=sched_eps, Q_init=None),
+        "greedy": lambda: qlearn_psrs(env, 10 ** 9, greedy_policy, gam, alpha=0.1, Q_init=None),
+        "soft": lambda: qlearn_psrs(env, 10 ** 9, soft_greedy_policy, gam, alpha=0.1, Q_init=None),
+        "saveq": lambda: qlearn_psrs(env, 12, epsilon_greedy_policy, gam, alpha=0.1, epsilon=0.2, Q_init=None, save_Q=1),
+        "es_sched": lambda: expSARSA_psrs(env, 12, pi, gam, alpha=sched_alpha, save_Q=1),
+    }
+    for s in d["seeds"]:
+        s = int(s)
+        for tag, fn in runs.items():
+            k = f"s{s}_{tag}"
+            np.random.seed(int(d[k + "_np_seed"]))
+            env.reset_sampler(s)
+            Q, info = fn()
+            after = np.random.random(3)
+            rows = d[k + "_rows"]
+            assert [int(m[6]["a"]) for m in info["memory"]] == [int(d["in_a"][r]) for r in rows], (tag, "accepted rows")
+            if tag.startswith("es_"):  # expected SARSA: Q[S_] @ pi[S_] is BLAS in the reference (rounding only)
+                assert np.abs(Q - d[k + "_Q"]).max() <= 1e-12 and np.abs(info["Qs"] - d[k + "_Qs"]).max() <= 1e-12
+            else:
+                assert np.array_equal(Q, d[k + "_Q"]), tag
+                assert np.array_equal(info["TD_errors"], d[k + "_td"]), tag
+                if tag == "saveq":
+                    assert np.array_equal(info["Qs"], d[k + "_Qs"])
+            assert np.array_equal(info["Gs"], d[k + "_Gs"]), tag
+            assert np.array_equal(np.array([m[5] for m in info["memory"]]), d[k + "_p"]), (tag, "behaviour distributions")
+            assert np.array_equal(after, d[k + "_after"]), (tag, "the global NumPy stream stands where the reference leaves it")
+
+
+def test_generic_kernels_after_a_keyed_sampler_reset(gpu):
+    """reset_sampler(seeds, policy=...) lays the queue orders out as candidate streams only; step(), step_single() and eval_td() walk
+    permutations and must see the SAME orders (rebuilt from the streams), not table order: compared with the oracle."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(3000, 25, 5, seed=5)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    pi = synth.dirichlet_policy(25, 5)
+    seeds = [3, 4, 5]
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds, policy=table.policy_slots(pi))
+    assert env.state.perm is None  # (keyed: streams only)
+    first = env.reset().cpu().numpy()
+    g = np.random.default_rng(0)
+    oras = []
+    for i, sd in enumerate(seeds):
+        o = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+        o.reset_sampler(sd)
+        assert o.reset() == first[i]
+        oras.append(o)
+    alive = np.ones(len(seeds), bool)
+    for it in range(200):
+        p_new = g.dirichlet(np.ones(5), size=len(seeds))
+        row, status, popped = (x.cpu().numpy() for x in env.step(p_new))
+        again = np.zeros(len(seeds), bool)
+        for i, o in enumerate(oras):
+            if not alive[i]:
+                continue
+            ref_row, ref_pop = o.step(p_new[i])
+            assert popped[i] == ref_pop, (it, i)
+            if ref_row is None:
+                assert status[i] == L.ST_EXHAUSTED
+                alive[i] = False
+                continue
+            assert status[i] == L.ST_OK and int(row[i]) == ref_row, (it, i)
+            if e["terminals"][ref_row]:
+                again[i] = True
+        if again.any():
+            nxt = env.reset(mask=torch.from_numpy(again).to(gpu)).cpu().numpy()
+            for i in np.nonzero(again)[0]:
+                ref = oras[i].reset()
+                assert (ref is None and nxt[i] < 0) or ref == nxt[i]
+                if ref is None:
+                    alive[i] = False
+    # eval_td after a keyed reset walks the same orders too: its accepted rows equal a plain (permutation) reset's
+    from rl_offline_simulation_amd import _lib
+    env.reset_sampler(seeds, policy=table.policy_slots(pi))
+    a = env.eval_td(table.policy_slots(pi), 0.9, _lib.TD_EXPSARSA, 0.1, trace_cap=3001)
+    env.reset_sampler(seeds)
+    b = env.eval_td(table.policy_slots(pi), 0.9, _lib.TD_EXPSARSA, 0.1, trace_cap=3001)
+    assert torch.equal(a["trace_row"], b["trace_row"]) and torch.equal(a["q"], b["q"])
+
+
+def test_lds_atomic_order_selftest(gpu):
+    """The hardware property the scan's queue positions rely on (one ds_add_rtn_u32, same address: ascending lane order)."""
+    from rl_offline_simulation_amd import _lib as L
+    out = torch.full((1,), -1, dtype=torch.int64, device=gpu)
+    L.check(L.load().offsim_selftest_lds_atomic_order(out.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(out[0]) == 0
