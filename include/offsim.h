@@ -265,6 +265,17 @@ int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, const uint64
                         const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes, const offsim_evalmc_out *out,
                         void *stream);
 
+/* Faults of asynchronous kernels.  Every wait of one wavefront for another (the shuffle's ring protocol, the scan's chain / helper
+ * hand-off) is bounded; a wait that gives up ends its workgroup instead of hanging the stream and raises a bit here:
+ *   OFFSIM_FAULT_SHUFFLE  offsim_shuffle_queues[_keys]: the orders that call wrote are invalid
+ *   OFFSIM_FAULT_SCAN     offsim_eval_mc_streams: the rollouts concerned also report OFFSIM_ST_PROTOCOL
+ * offsim_async_faults() returns the bits raised on the current device since its last call and clears them (>= 0; negative: OFFSIM_E*).
+ * The entry points themselves return before their kernels run: synchronise the stream first.  No fault has ever been observed in a
+ * product build; tests/test_gpu_round3.py raises one with a -DSHUF_FAULT_INJECT build. */
+#define OFFSIM_FAULT_SHUFFLE 1
+#define OFFSIM_FAULT_SCAN 2
+int offsim_async_faults(void);
+
 /* Self-test of the hardware property the headline scan relies on beyond the ISA manual: the LDS applies the lanes of one
  * ds_add_rtn_u32 that hit the same address in ascending lane order (csrc/scan_rows.hpp takes the queue positions of a tick's
  * accepted candidates that way).  *mismatches (device, int64) receives the number of lane operations that returned anything

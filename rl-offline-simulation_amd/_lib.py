@@ -88,6 +88,7 @@ SIGNATURES = {
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
     "offsim_selftest_lds_atomic_order": (C.c_int, [_vp, _vp]),
+    "offsim_async_faults": (C.c_int, []),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
     "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
 }
@@ -117,6 +118,20 @@ def load():
 def check(rc):
     if rc != OK:
         raise OffsimError(f"offsim error {rc}: {load().offsim_last_error().decode()}")
+
+
+FAULT_SHUFFLE, FAULT_SCAN = 1, 2
+
+
+def check_async_faults():
+    """Raise if a kernel gave up a bounded inter-wavefront wait since the last check (include/offsim.h: offsim_async_faults).
+    Call with the stream synchronised -- the host-facing drivers do, after they have copied their results back."""
+    v = load().offsim_async_faults()
+    if v < 0:
+        check(v)
+    if v:
+        what = [n for b, n in ((FAULT_SHUFFLE, "sampler reset (shuffle ring protocol)"), (FAULT_SCAN, "scan (chain / helper hand-off)")) if v & b]
+        raise OffsimError("a kernel gave up a bounded wait instead of hanging: " + ", ".join(what) + "; the results of that call are invalid")
 
 
 def require_device():

@@ -318,6 +318,16 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     return OFFSIM_OK;
 }
 
+// Fault bits raised by asynchronous kernels of this device since the last call (and cleared by it): OFFSIM_FAULT_SHUFFLE -- a role of
+// the shuffle's ring protocol gave up a bounded wait (the orders of that call are invalid); OFFSIM_FAULT_SCAN -- the same in the scan
+// (those rollouts also carry OFFSIM_ST_PROTOCOL).  Synchronise the stream the kernels ran on first.
+extern "C" int offsim_async_faults(void) {
+    int32_t v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(offsim::g_async_fault), sizeof(v)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: read failed%s");
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(offsim::g_async_fault), &zero, sizeof(zero)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: clear failed%s");
+    return v;
+}
+
 extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out,
                                      uint32_t *init_perm_out, void *stream) {
     if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");

@@ -40,6 +40,7 @@
 #include "offsim.h"
 #include "pcg64_dev.hpp"
 #include "scan_win.hpp"  // pack_key / key_T, lds_u32
+#include "shuffle_wave.hpp"  // g_async_fault
 
 namespace offsim {
 
@@ -1193,6 +1194,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             out.steps[r] = steps;
             out.cand[r] = c;
             out.status[r] = status;
+            if (status == OFFSIM_ST_PROTOCOL) atomicOr(&g_async_fault, OFFSIM_FAULT_SCAN);
 #ifdef OFFSIM_ROWS_PROF
             if (out.dbg) {
                 out.dbg[4 * r + 0] = (int64_t)pf_fast;

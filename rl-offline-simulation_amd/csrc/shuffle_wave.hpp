@@ -43,7 +43,26 @@ namespace offsim {
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
-enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8, SH_CSTOP = 9 };  // words of the control block
+enum { SH_GEN0 = 0, SH_GEN1 = 1, SH_CPUB = 2, SH_FILL = 3, SH_TAIL = 4, SH_DONE = 5, SH_ATOP = 6, SH_EM0 = 7, SH_EM1 = 8, SH_CSTOP = 9,
+       SH_ABORT = 10 };  // words of the control block
+__device__ int32_t g_async_fault = 0;  // fault bits of asynchronous kernels on this device (offsim_async_faults, include/offsim.h)
+// Every wait of one role for another is bounded.  A role that has polled SHUF_SPIN_LIMIT times (with s_sleep: ~0.1 s, five orders of
+// magnitude beyond any legitimate wait) raises SH_ABORT; a role that finds SH_ABORT raised -- it looks every 1024 polls of a wait, so
+// nothing of this sits on a common path -- raises OFFSIM_FAULT_SHUFFLE and ENDS (a wavefront that has ended no longer counts at the
+// workgroup's barriers).  A slip of the ring protocol then costs the call its result (offsim_async_faults), not the stream.
+#define SHUF_SPIN_LIMIT (1u << 20)
+__device__ __noinline__ void shuf_bound_check(volatile __attribute__((address_space(3))) uint32_t *ctrl, uint32_t polls) {
+    if (polls > SHUF_SPIN_LIMIT) ctrl[SH_ABORT] = 1u;
+    if (ctrl[SH_ABORT]) {
+        if ((threadIdx.x & 63u) == 0u) atomicOr(&g_async_fault, OFFSIM_FAULT_SHUFFLE);
+        __builtin_amdgcn_endpgm();
+    }
+}
+__device__ __forceinline__ void shuf_bound(volatile __attribute__((address_space(3))) uint32_t *ctrl, uint32_t &polls) {
+#ifndef SHUF_NO_BOUND  // (SHUF_NO_BOUND: timing experiment only -- what the bound costs)
+    if (__builtin_expect((++polls & 1023u) == 0u, 0)) shuf_bound_check(ctrl, polls);  // (out of line: the waits keep their shape)
+#endif
+}
 #define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
 
 // explicit LDS address space: keeps every ring / segment access a ds_* instruction (a generic pointer would make
@@ -213,7 +232,9 @@ __global__ void __launch_bounds__(256)
             for (;;) {
                 bool stop = false;
                 SPW0();
+                uint32_t polls = 0;
                 while ((blk + 1u) * 128u - cpub > SHUF_RG) {
+                    shuf_bound(ctrl, polls);
                     if (sh_ld(ctrl + SH_DONE)) {
                         stop = true;
                         break;
@@ -252,20 +273,28 @@ __global__ void __launch_bounds__(256)
             auto wait_draws = [&](uint32_t upto) {
                 const bool waited = upto > avail;
                 if (waited) SPW0();
+                uint32_t polls = 0;
                 while (upto > avail) {
                     const uint64_t gg = *(lds_vu64 *)(ctrl + SH_GEN0);
                     const uint32_t g0 = sh_rfl((uint32_t)gg), g1 = sh_rfl((uint32_t)(gg >> 32));
                     avail = 128u * (g0 <= g1 ? 2u * g0 : 2u * g1 + 1u);  // contiguous blocks
-                    if (upto > avail) __builtin_amdgcn_s_sleep(1);
+                    if (upto > avail) {
+                        shuf_bound(ctrl, polls);
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                 }
                 if (waited) SPW1();
             };
             auto wait_room = [&](uint32_t upto) {  // the j ring may hold entries [tail, tail + SQ)
                 const bool waited = upto - tail > SHUF_SQ;
                 if (waited) SPW0();
+                uint32_t polls = 0;
                 while (upto - tail > SHUF_SQ) {
                     tail = sh_ld(ctrl + SH_TAIL);
-                    if (upto - tail > SHUF_SQ) __builtin_amdgcn_s_sleep(1);
+                    if (upto - tail > SHUF_SQ) {
+                        shuf_bound(ctrl, polls);
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                 }
                 if (waited) SPX1();  // C: waiting for room in the j ring (A behind)
             };
@@ -384,12 +413,19 @@ __global__ void __launch_bounds__(256)
             // full groups: no lane masks anywhere on the common path.  (Fetching the next group's partners early was
             // measured slower: this wavefront is bound by the instructions it issues, not by the LDS round trips.)
             const uint32_t lo = stop_i - 1u;  // the chain's steps are i_top .. lo + 1
+#ifdef SHUF_FAULT_INJECT  // (test build: this role never starts, so the others run into their bounds -- and so does this wait)
+            for (uint32_t polls = 0;; __builtin_amdgcn_s_sleep(1)) shuf_bound(ctrl, polls);
+#endif
             while (i_top >= 64u + lo) {
                 if (fill - done < 64u) {
                     SPW0();
+                    uint32_t polls = 0;
                     while (fill - done < 64u) {
                         fill = sh_ld(ctrl + SH_FILL);
-                        if (fill - done < 64u) __builtin_amdgcn_s_sleep(1);
+                        if (fill - done < 64u) {
+                            shuf_bound(ctrl, polls);
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                     }
                     SPW1();
                 }
@@ -417,9 +453,13 @@ __global__ void __launch_bounds__(256)
             }
             if (i_top > lo) {  // the last, partial group
                 const uint32_t cnt = i_top - lo;
+                uint32_t polls = 0;
                 while (fill - done < cnt) {
                     fill = sh_ld(ctrl + SH_FILL);
-                    if (fill - done < cnt) __builtin_amdgcn_s_sleep(1);
+                    if (fill - done < cnt) {
+                        shuf_bound(ctrl, polls);
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                 }
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 const uint32_t il = i_top - (uint32_t)lane;

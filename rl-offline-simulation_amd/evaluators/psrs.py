@@ -391,6 +391,7 @@ def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffl
         o = env.eval_mc(pi_slots, gamma, n_episodes)
         for k in outs:
             outs[k].append(o[k].cpu().numpy())
+        L.check_async_faults()  # (the copies above synchronised the stream)
     res = {k: np.concatenate(v) for k, v in outs.items()}
     with np.errstate(invalid="ignore", divide="ignore"):
         res["value"] = res["sum_g"] / res["n_ep"]

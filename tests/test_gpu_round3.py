@@ -150,3 +150,56 @@ def test_lds_atomic_order_selftest(gpu):
     L.check(L.load().offsim_selftest_lds_atomic_order(out.data_ptr(), L.stream_ptr()))
     torch.cuda.synchronize()
     assert int(out[0]) == 0
+
+
+def test_shuffle_protocol_slip_ends_with_an_error_not_a_hang(gpu):
+    """A build whose applier role never starts (-DSHUF_FAULT_INJECT, rl-offline-simulation_amd/csrc/variants/lib_fault.so): the
+    classifier runs into the bound of its wait for room in the j ring, every role leaves, the call returns within seconds and
+    offsim_async_faults() / check_async_faults() report it.  Run in a child process (the library is chosen per process)."""
+    import os, subprocess, sys, time
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT"],
+                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    code = """
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch
+from rl_offline_simulation_amd import synth, _lib as L
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+e = synth.synth_iid(20000, 25, 5, seed=1)
+t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+env = BatchedPSRS(t, 8)
+assert L.load().offsim_async_faults() == 0
+t0 = time.time()
+env.reset_sampler(list(range(8)))
+torch.cuda.synchronize()
+dt = time.time() - t0
+v = L.load().offsim_async_faults()
+print("FAULTS", v, "SECONDS", round(dt, 2))
+assert v & L.FAULT_SHUFFLE and dt < 5.0
+env.reset_sampler(list(range(8)))
+torch.cuda.synchronize()
+try:
+    L.check_async_faults()
+except L.OffsimError as ex:
+    print("RAISED", ex)
+else:
+    raise SystemExit("check_async_faults did not raise")
+""" % os.path.dirname(here)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OFFSIM_LIB=lib), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RAISED" in r.stdout and "FAULTS" in r.stdout
+    # and the product build raises nothing on the same job
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(20000, 25, 5, seed=1)
+    t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    env = BatchedPSRS(t, 8)
+    env.reset_sampler(list(range(8)))
+    torch.cuda.synchronize()
+    L.check_async_faults()
