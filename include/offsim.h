@@ -297,7 +297,8 @@ int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
  *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide 21-bit digest ties
  *   exactly.  Strides are in elements; stride 0 = one order shared by all rollouts; loc == NULL = queues in table order
  *   (dig = dig32 itself, stride 0).  ro->perm / perm_stride are ignored; ro->init_perm is used as everywhere else.
- *   n_slots <= 256. */
+ *   n_slots <= 256. * offsim_eval_mc_streams returns OFFSIM_EUNSUPPORTED unless offsim_table.max_seg is set and <= 65536 (with or without `loc`):
+ * queue positions travel in 17-bit descriptor fields. */
 typedef struct offsim_streams {
     const uint32_t *dig;
     int64_t dig_stride;

@@ -1200,6 +1200,9 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: candidate windows support at most 256 states%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
+    // positions inside a state's queue travel in 17-bit fields of the request descriptors and as 16-bit local rows (loc)
+    if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > 65536))
+        return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (use offsim_eval_mc_keys)%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool trace = out->trace_row || out->trace_pop;

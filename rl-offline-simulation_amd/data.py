@@ -153,6 +153,20 @@ class _PickledSpace:
         return spaces.Box(d["low"], d["high"], shape, np.dtype(d.get("dtype", np.float32)).type)
 
 
+class _Inert:
+    """Stands in for numpy.random's pickle helpers (__generator_ctor, __bit_generator_ctor, PCG64, SeedSequence, ...): callable,
+    accepts any state, does nothing."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+    def __setstate__(self, state):
+        pass
+
+
 def restricted_loads(data):
     """pickle.loads for the attributes the reference stores in its HDF5 files (data.py:88-91): gym.spaces.Discrete / Box map
     onto this package's spaces, offsim4rl.data.ProbDistribution onto the local enum, NumPy array / dtype reconstruction is
@@ -178,6 +192,10 @@ def restricted_loads(data):
             if (module, name) == ("copyreg", "_reconstructor") or (module, name) == ("builtins", "object"):
                 import copyreg
                 return copyreg._reconstructor if name == "_reconstructor" else object
+            # a space that has been seeded or sampled carries its np_random Generator (gym.spaces.Space._np_random); nothing of it
+            # is needed: its constructors and bit generators unpickle into an inert placeholder instead of being imported
+            if module.startswith("numpy.random"):
+                return _Inert
             raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a dataset file")
 
     obj = U(io.BytesIO(data)).load()

@@ -23,25 +23,32 @@ SHUFFLE_NONE = "table_order"         # queues in buffer order (no shuffle); per-
 
 
 _GP_CACHE = {}
+_GP_CACHE_BYTES = 256 << 20
 
 
 def _gamma_pow(gamma, n, device, cap=None):
     """gamma**t exactly as the host computes it for the reference (Python float ** int == libm pow, psrs.py:262), for every
     t an episode can reach: at least `n` entries, then on until the factor is stationary (0, inf or 1: the device clamps t to
-    the last entry in that case, csrc/discount.hpp) or `cap` entries (an episode has at most N steps) are there."""
+    the last entry in that case, csrc/discount.hpp) or `cap` entries (an episode has at most N steps) are there.  Built in
+    blocks of 65536 with Python's own `float ** int` (NumPy's array pow is vectorised differently and differs in the last bit for
+    some t), so a gamma below 1 stops after the block its factor underflows in; the cache is bounded by bytes (_GP_CACHE_BYTES)."""
     g = float(gamma)
     cap = max(int(n), 2) if cap is None else max(int(cap), int(n), 2)
     key = (g, int(n), cap, str(device))
     if key not in _GP_CACHE:
-        vals = [g ** t for t in range(max(int(n), 2))]
-        while len(vals) < cap and not (vals[-1] == vals[-2] and (vals[-1] in (0.0, 1.0) or vals[-1] in (float("inf"), float("-inf")))):
-            t0 = len(vals)
-            vals.extend(g ** t for t in range(t0, min(cap, t0 + 65536)))
-        while len(vals) > max(int(n), 2) and vals[-1] == vals[-2] == vals[-3] and vals[-1] in (0.0, 1.0, float("inf"), float("-inf")):
-            vals.pop()  # (extended in blocks: keep exactly two stationary entries)
-        if len(_GP_CACHE) > 64:
+        stationary = lambda v: len(v) >= 2 and v[-1] == v[-2] and (v[-1] in (0.0, 1.0) or np.isinf(v[-1]))
+        blocks, total = [], 0
+        while total < max(int(n), 2) or (total < cap and not stationary(blocks[-1])):
+            m = min(65536, (max(int(n), 2) if total < max(int(n), 2) else cap) - total)
+            blocks.append(np.array([g ** t for t in range(total, total + m)], dtype=np.float64))  # (Python's own pow: NumPy's array pow is not bit-identical)
+            total += m
+        vals = np.concatenate(blocks)
+        keep = len(vals)
+        while keep > max(int(n), 2) and vals[keep - 1] == vals[keep - 2] == vals[keep - 3] and (vals[keep - 1] in (0.0, 1.0) or np.isinf(vals[keep - 1])):
+            keep -= 1  # (extended in blocks: keep exactly two stationary entries)
+        if sum(v.numel() * 8 for v in _GP_CACHE.values()) + keep * 8 > _GP_CACHE_BYTES:
             _GP_CACHE.clear()
-        _GP_CACHE[key] = torch.tensor(vals, dtype=torch.float64, device=device)
+        _GP_CACHE[key] = torch.from_numpy(vals[:keep].copy()).to(device)
     return _GP_CACHE[key]
 
 
@@ -133,12 +140,14 @@ class BatchedPSRS:
 
     @staticmethod
     def _policy_key(policy):
+        """What identifies the tabular policy the streams / compiled keys were made for: shape, dtype and the bytes themselves (a
+        few KB; compared for equality, not by hash)."""
         p = policy.detach().cpu().numpy() if isinstance(policy, torch.Tensor) else np.asarray(policy)
-        return (p.shape, p.dtype.str, hash(np.ascontiguousarray(p).tobytes()))
+        return (p.shape, p.dtype.str, np.ascontiguousarray(p).tobytes())
 
-    def _policy_keys(self, policy):
+    def _policy_keys(self, policy, key=None):
         """(compiled 64-bit keys, their 32-bit digests) of `policy` on the device, cached per policy."""
-        k = self._policy_key(policy)
+        k = self._policy_key(policy) if key is None else key
         if getattr(self, "_pk_cache", None) is None or self._pk_cache[0] != k:
             t = self.table
             pi_d = torch.as_tensor(np.ascontiguousarray(policy) if not isinstance(policy, torch.Tensor) else policy,
@@ -150,7 +159,7 @@ class BatchedPSRS:
             self._pk_cache = (k, keys, self._dig32)
         return self._pk_cache[1], self._pk_cache[2]
 
-    def _derive_streams(self, policy, max_entries=1 << 26):
+    def _derive_streams(self, policy, max_entries=1 << 26, key=None):
         """Candidate streams from queue orders that exist as permutations (reset_sampler without `policy`): one gather, done
         for jobs of up to `max_entries` queue positions; bigger jobs pass `policy` to reset_sampler or run the window kernels."""
         t, st = self.table, self.state
@@ -159,8 +168,8 @@ class BatchedPSRS:
         n_rows = 1 if (st.perm is None or st.perm_stride == 0) else self.R
         if n_rows * t.N > max_entries:
             return
-        keys, dig32 = self._policy_keys(policy)
-        key = self._policy_key(policy)
+        key = self._policy_key(policy) if key is None else key
+        keys, dig32 = self._policy_keys(policy, key=key)
         if st.perm is None:  # table order
             self._streams = dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=key)
             return
@@ -279,11 +288,12 @@ class BatchedPSRS:
             fast = can_fast
         if fast and not can_fast:
             raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule and <= 256 states")
-        if fast and not (self._streams is not None and self._streams["key"] == self._policy_key(pi_slots)):
-            self._derive_streams(pi_slots)  # small jobs: the streams are gathered from the permutations on the spot
-        rows = bool(fast) and self._streams is not None and self._streams["key"] == self._policy_key(pi_slots)
+        pkey = self._policy_key(pi_slots) if fast else None  # (once per call: a device tensor is copied to the host for it)
+        if fast and not (self._streams is not None and self._streams["key"] == pkey):
+            self._derive_streams(pi_slots, key=pkey)  # small jobs: the streams are gathered from the permutations on the spot
+        rows = bool(fast) and self._streams is not None and self._streams["key"] == pkey
         if rows:  # the sampler reset laid the orders out as candidate streams for this policy: row-packed scan
-            keys, _ = self._policy_keys(pi_slots)
+            keys, _ = self._policy_keys(pi_slots, key=pkey)
             sm = self._streams
             smc = L.Streams(dig=L.ptr(sm["dig"]), dig_stride=sm["dig_stride"], loc=L.ptr(sm["loc"]), loc_stride=sm["loc_stride"])
             L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
@@ -370,16 +380,23 @@ class BatchedPSRS:
         return self._keys
 
 
+def rollout_resident_bytes(table, keyed=True):
+    """HBM one rollout keeps resident between reset_sampler and the scan: its queue orders (candidate streams: 4 + 2 bytes per queue
+    position; as permutations: 4), its init order, cursors and random-stream state."""
+    return int(table.N) * (6 if keyed else 4) + int(table.N0) * 4 + int(table.n_slots) * 4 + 64
+
+
 def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, tile=None,
                     reject_mode=L.REJECT_DEFAULT, n_episodes=None):
-    """evalMC_psrs for many sampler seeds.  Rollouts are processed in tiles of `tile` seeds so that the per-rollout
-    queue permutations (4*N bytes each) fit the HBM budget.  Returns host arrays: sum_g, n_ep, steps, cand, status
+    """evalMC_psrs for many sampler seeds.  Rollouts are processed in tiles of `tile` seeds so that the per-rollout queue orders
+    (rollout_resident_bytes each) fit the device's free memory.  Returns host arrays: sum_g, n_ep, steps, cand, status
     and value = sum_g / n_ep (the per-seed value estimate, Gs.mean())."""
     seeds = np.asarray(seeds, dtype=np.uint64)
     R = len(seeds)
     if tile is None:
-        budget = 48 << 30  # bytes of permutation indices kept resident at once
-        tile = R if shuffle != SHUFFLE_PER_ROLLOUT else int(max(1, min(R, budget // max(4 * table.N, 1))))
+        free_b, _ = torch.cuda.mem_get_info(table.device)
+        per = rollout_resident_bytes(table, keyed=True)
+        tile = R if shuffle != SHUFFLE_PER_ROLLOUT else int(max(1, min(R, (free_b - (2 << 30)) // per)))
     pi_slots = table.policy_slots(pi)
     outs = {k: [] for k in ("sum_g", "n_ep", "steps", "cand", "status")}
     env = None

@@ -261,3 +261,55 @@ def test_discount_table_runs_until_the_factor_is_stationary():
     assert len(_gamma_pow(0.99, 4096, torch.device("cpu"), cap=5000)) == 5000  # an episode cannot be longer than the log
     assert len(_gamma_pow(1.0, 16, torch.device("cpu"), cap=10 ** 6)) == 16     # already stationary
     assert len(_gamma_pow(0.5, 4096, torch.device("cpu"), cap=10 ** 6)) == 4096
+
+
+def test_restricted_loads_reads_pickled_gym_spaces_including_seeded_ones():
+    """The reference stores pickle.dumps(gym.spaces.*) in its HDF5 attributes (offsim4rl/data.py:88-91).  gym itself is not in this
+    image, so the pickles are made here from classes that sit at gym's module paths and pickle the way gym.spaces.Space does (class +
+    __dict__, incl. a seeded space's `_np_random` Generator -- a real numpy Generator, pickled by numpy's own reducers); loading needs
+    no gym, imports nothing of it, keeps nothing of the Generator, and still refuses arbitrary callables."""
+    import pickle, sys, types
+    from rl_offline_simulation_amd import spaces
+    from rl_offline_simulation_amd.data import restricted_loads
+    mods = {}
+    for name in ("gym", "gym.spaces", "gym.spaces.space", "gym.spaces.discrete", "gym.spaces.box"):
+        mods[name] = types.ModuleType(name)
+
+    class Space:
+        def __init__(self, shape=None, dtype=None, seed=None):
+            self._shape, self.dtype = shape, None if dtype is None else np.dtype(dtype)
+            self._np_random = None if seed is None else np.random.default_rng(seed)
+    Space.__module__, Space.__qualname__ = "gym.spaces.space", "Space"
+
+    class Discrete(Space):
+        def __init__(self, n, seed=None, start=0):
+            self.n, self.start = int(n), int(start)
+            super().__init__((), np.int64, seed)
+    Discrete.__module__, Discrete.__qualname__ = "gym.spaces.discrete", "Discrete"
+
+    class Box(Space):
+        def __init__(self, low, high, shape, dtype=np.float32, seed=None):
+            self.low, self.high = np.full(shape, low, dtype), np.full(shape, high, dtype)
+            self.bounded_below, self.bounded_above = np.isfinite(self.low), np.isfinite(self.high)
+            super().__init__(tuple(shape), dtype, seed)
+    Box.__module__, Box.__qualname__ = "gym.spaces.box", "Box"
+    mods["gym.spaces.space"].Space, mods["gym.spaces.discrete"].Discrete, mods["gym.spaces.box"].Box = Space, Discrete, Box
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        blobs = [pickle.dumps(Discrete(7)), pickle.dumps(Discrete(5, seed=3)), pickle.dumps(Box(-1.5, 2.0, (4,), np.float32, seed=11))]
+        seeded = Discrete(5, seed=3)
+        seeded._np_random.integers(0, 5)  # (a space that has been sampled from)
+        blobs.append(pickle.dumps(seeded))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert b"numpy.random" in blobs[1]  # the Generator is in the stream
+    got = [restricted_loads(b) for b in blobs]
+    assert isinstance(got[0], spaces.Discrete) and got[0].n == 7 and got[1].n == 5 and got[3].n == 5
+    assert isinstance(got[2], spaces.Box) and got[2].shape == (4,) and np.allclose(got[2].low, -1.5) and np.allclose(got[2].high, 2.0)
+    with pytest.raises(pickle.UnpicklingError):
+        restricted_loads(pickle.dumps(os.system))

@@ -203,3 +203,18 @@ else:
     env.reset_sampler(list(range(8)))
     torch.cuda.synchronize()
     L.check_async_faults()
+
+
+def test_bench_two_ranks_on_one_device(gpu):
+    """The whole multi-rank bench path -- launcher, episode shards, per-rank tile from the free HBM, all-reduce of the per-seed
+    estimates, parity check against the oracle -- with both ranks on this box's one GPU (gloo; RCCL needs two)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--dist-backend", "gloo",
+                        "--transitions", "2000000", "--rollouts", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["parity_check"]["ok"]
+    assert line["config"]["rollout_tile"] == 256 and line["config"]["queue_orders_resident_bytes_rank0"] > 256 * 6 * 900000
+    assert line["rollout_sharded"]["rollouts_per_gpu"] == 128
