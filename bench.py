@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--tile", type=int, default=0, help="rollouts whose queue orders are resident at once (0 = as many as the free HBM of the "
                                                        "rank holds: 6 bytes per queue position as candidate streams, 4 as permutations)")
     ap.add_argument("--gamma", type=float, default=0.99)
+    ap.add_argument("--rng", default="pcg64", choices=["pcg64", "philox"],
+                    help="rejection stream provider: pcg64 = NumPy's default_rng (the reference's numbers, the headline); philox = rocRAND's "
+                         "Philox4x32-10 device API in the generic kernel (another sample path: no oracle re-run, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
@@ -343,7 +346,9 @@ def run(a):
                 if record:
                     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                     e0.record()
-                env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots)
+                env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots if a.rng == "pcg64" else None)
+                if a.rng == "philox":
+                    env.set_rejection_seeds(sd, provider="philox")
                 if record:
                     e1.record()
                 o = env.eval_mc(pi_slots, a.gamma)
@@ -381,7 +386,7 @@ def run(a):
         res = dict(elapsed=float(el_t[0]), steps_pass=float(tot[0]), cand_pass=float(tot[1]), t_scan=t_scan, t_reset=t_reset,
                    n_scan=sum(1 for k, _, _ in ev if k == "scan"), my_steps=float(acc["steps"].sum()), my_cand=float(acc["cand"].sum()),
                    est=est, acc={k: v.cpu().numpy() for k, v in acc.items()}, b_c=table.bytes_per_candidate, b_s=table.bytes_per_step,
-                   rows=table.N, tile=tile, variant=env_for(tile).scan_variant(), seg=(table.min_seg, table.max_seg),
+                   rows=table.N, tile=tile, variant=env_for(tile).scan_variant() if a.rng == "pcg64" else "k_eval_mc", seg=(table.min_seg, table.max_seg),
                    resident=int(resident), hbm_free=int(free_b), hbm_total=int(total_b))
         del envs, table
         torch.cuda.empty_cache()
@@ -425,7 +430,7 @@ def run(a):
             "config": {"workload": f"{wl}, {a.transitions} transitions {'in total' if strong else 'per GPU'} x {R} rollouts, evalMC_psrs to exhaustion, gamma={a.gamma}",
                        "transitions": a.transitions, "transitions_on_rank0": n_rank, "rollouts": R, "shuffle": a.shuffle, "rollout_tile": m["tile"],
                        "queue_orders_resident_bytes_rank0": m["resident"], "hbm_free_bytes_rank0": m["hbm_free"], "hbm_total_bytes_rank0": m["hbm_total"],
-                       "p_log": "f32", "sharding": shard_txt, "segment_rows_min_max": list(m["seg"])},
+                       "p_log": "f32", "rng": a.rng, "sharding": shard_txt, "segment_rows_min_max": list(m["seg"])},
             "candidates_per_s": m["cand_pass"] * a.steps / elapsed, "acceptance": m["steps_pass"] / max(m["cand_pass"], 1.0),
             "buffer_consumed_frac": m["cand_pass"] / (R * a.transitions * (1 if strong else world)),
             "value_estimate_mean": float(np.nanmean(vest)),
@@ -440,7 +445,7 @@ def run(a):
         if extra:
             out["rollout_sharded"] = extra
         base = None
-        if not a.no_parity_check and a.shuffle != "table_order":  # (the reference has no unshuffled mode to compare with)
+        if not a.no_parity_check and a.shuffle != "table_order" and a.rng == "pcg64":  # (the reference has no unshuffled mode; the C oracle draws from PCG64)
             base = oracle_for(e)
             ps = [s for s in PARITY_SEEDS if s < R]
             got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ps}

@@ -93,7 +93,19 @@ typedef struct offsim_rollouts {
     int64_t perm_stride;
     const uint32_t *init_perm; /* init_perm[r*init_stride + k] = index into init_slot/init_orig   */
     int64_t init_stride;
+    int32_t rng_kind;       /* OFFSIM_STREAM_*: what `rng` holds and which generator draws u (psrs.py:56)  */
 } offsim_rollouts;
+/* Provider of the rejection stream u ~ U (one draw per candidate examined, psrs.py:56):
+ *   OFFSIM_STREAM_PCG64   NumPy's default_rng(seed).random(): u in [0,1).  The parity default: accepted-index sequences equal the
+ *                         reference's bit for bit.  rng row = PCG64 state hi, lo, increment hi, lo (offsim_seed_streams).
+ *   OFFSIM_STREAM_PHILOX  rocRAND's Philox4x32-10 through its device API (rocrand_init(seed, 0, 2 i) / rocrand): draw i of a rollout is
+ *                         rocrand_uniform_double of the engine seeded with the rollout's seed, u in (0,1] -- a different, equally valid
+ *                         sample path, NOT the reference's numbers; its oracle is the reference's own PSRS.step with
+ *                         env.rejection_sampling_rng replaced by an object that replays this stream (tests/golden/make_golden.py).
+ *                         rng row = seed, draws consumed so far, 0, 0.  Taken by offsim_step_batch, offsim_eval_mc and offsim_eval_td;
+ *                         the compiled-policy scans (offsim_eval_mc_keys / _streams) are PCG64-only and return OFFSIM_EUNSUPPORTED. */
+#define OFFSIM_STREAM_PCG64 0
+#define OFFSIM_STREAM_PHILOX 1
 
 const char *offsim_last_error(void);
 int offsim_version(void);

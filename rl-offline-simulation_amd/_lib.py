@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("OFFSIM_LIB") or os.path.join(_HERE, "csrc", "liboffsi
 OK = 0
 F32, F64, F16 = 0, 1, 2
 REJECT_DEFAULT, REJECT_NEVER = 0, 1
+STREAM_PCG64, STREAM_PHILOX = 0, 1
 PROB_F64, PROB_F32 = 0, 1
 ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE, ST_PROTOCOL = 0, 1, 2, 3, 4, 5
 
@@ -29,7 +30,7 @@ class Table(C.Structure):
 class Rollouts(C.Structure):
     """struct offsim_rollouts"""
     _fields_ = [("R", _i32), ("rng", _vp), ("cursor", _vp), ("init_cursor", _vp), ("cur_slot", _vp),
-                ("perm", _vp), ("perm_stride", _i64), ("init_perm", _vp), ("init_stride", _i64)]
+                ("perm", _vp), ("perm_stride", _i64), ("init_perm", _vp), ("init_stride", _i64), ("rng_kind", _i32)]
 
 
 class EvalMCOut(C.Structure):

@@ -19,6 +19,8 @@
 #include "offsim.h"
 #include "discount.hpp"
 #include "pcg64_dev.hpp"
+#include <rocrand/rocrand_kernel.h>  // device API of Philox4x32-10 (the OFFSIM_STREAM_PHILOX provider)
+
 #include "shuffle_wave.hpp"
 
 using namespace offsim;
@@ -497,9 +499,21 @@ struct StepResult {
 
 // Per-wave jump table in LDS: entry d (1..64) advances the rollout's PCG64 stream by d draws.
 struct WaveRng {
-    U128 lane_state;  // state that yields draw (c + lane)
-    Jump *table;      // LDS, 65 entries
+    U128 lane_state;  // PCG64: state that yields draw (c + lane)
+    Jump *table;      // PCG64: LDS, 65 entries
+    int kind;         // OFFSIM_STREAM_*
+    uint64_t seed, c; // Philox: the rollout's seed, draws consumed so far (lane k looks at draw c + k)
 };
+
+// Draw i of the Philox provider as the 53-bit integer k with u = k * 2^-53: rocRAND's Philox4x32-10 through its device API, engine
+// (seed, subsequence 0) positioned on 32-bit output 2 i; rocrand_uniform_double of two outputs v1, v2 is
+// 2^-53 + (v1 | (v2 >> 11) << 32) * 2^-53 (rocrand_uniform.h), i.e. k = (v1 | (v2 >> 11) << 32) + 1 in [1, 2^53]: u in (0, 1].
+__device__ __forceinline__ uint64_t philox_k53(uint64_t seed, uint64_t i) {
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, 0ull, 2ull * i, &st);
+    const uint32_t v1 = rocrand(&st), v2 = rocrand(&st);
+    return ((uint64_t)v1 | ((uint64_t)(v2 >> 11) << 32)) + 1ull;
+}
 
 // One PSRS.step (psrs.py:39-51).  All arguments wave-uniform except what lanes load.
 // PROB = double (F64 mode, any p_log type) or float (F32 mode, p_log float).
@@ -549,7 +563,7 @@ __device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uin
         if (reject_mode == OFFSIM_REJECT_NEVER) {
             acc = valid;
         } else {
-            uint64_t k53 = pcg_output(rng.lane_state) >> 11;
+            const uint64_t k53 = rng.kind == OFFSIM_STREAM_PHILOX ? philox_k53(rng.seed, rng.c + (uint64_t)lane) : pcg_output(rng.lane_state) >> 11;
             bool rej;
             if constexpr (sizeof(PROB) == 4) rej = rejects_f32((const float *)plog, (int64_t)g, a, (const float *)pnew, nA, k53);
             else rej = rejects_f64<PL>(plog, (int64_t)g, a, (const double *)pnew, nA, k53);
@@ -566,8 +580,12 @@ __device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uin
         cur += d;
         res.popped += d;
         if (reject_mode != OFFSIM_REJECT_NEVER) {  // every examined candidate consumed exactly one draw (psrs.py:56)
-            Jump j = rng.table[d];
-            rng.lane_state = pcg_apply(j, rng.lane_state);
+            if (rng.kind == OFFSIM_STREAM_PHILOX) {
+                rng.c += d;
+            } else {
+                Jump j = rng.table[d];
+                rng.lane_state = pcg_apply(j, rng.lane_state);
+            }
             consumed += d;
         }
         if (f >= 0) {
@@ -584,9 +602,13 @@ __device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uin
 }
 
 // Fill the per-wave jump table and position lane k on draw k of the stream that starts at `base`.
-__device__ __forceinline__ void wave_rng_init(WaveRng &rng, Jump *table, U128 base, U128 inc) {
+__device__ __forceinline__ void wave_rng_init(WaveRng &rng, Jump *table, U128 base, U128 inc, int kind = OFFSIM_STREAM_PCG64) {
     const int lane = threadIdx.x & (WAVE - 1);
     rng.table = table;
+    rng.kind = kind;
+    rng.seed = base.hi;  // (Philox: the rng row is seed, draws consumed, 0, 0)
+    rng.c = base.lo;
+    if (kind == OFFSIM_STREAM_PHILOX) return;
     Jump mine = pcg_jump(inc, (uint64_t)lane + 1);
     table[lane + 1] = mine;
     if (lane == 0) {
@@ -621,13 +643,16 @@ __global__ void __launch_bounds__(256) k_step_batch(offsim_table t, offsim_rollo
     WaveRng rng;
     U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
     U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
-    if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc);
+    rng.kind = ro.rng_kind;
+    if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc, ro.rng_kind);
     uint64_t consumed = 0;
     const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
     StepResult s = psrs_step<PL, PROB>(t, t.seg_off, perm_row, slot, ro.cursor + (int64_t)r * t.n_slots,
                                        p_new + (int64_t)r * t.nA, reject_mode, max_pop, rng, consumed);
     if (lane == 0) {
-        if (consumed) {
+        if (consumed && ro.rng_kind == OFFSIM_STREAM_PHILOX) {
+            ro.rng[4 * r + 1] = base.lo + consumed;
+        } else if (consumed) {
             U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
             ro.rng[4 * r + 0] = nb.hi;
             ro.rng[4 * r + 1] = nb.lo;
@@ -725,7 +750,7 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     WaveRng rng;
     U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
     U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
-    wave_rng_init(rng, tables + wave * (WAVE + 1), base, inc);
+    wave_rng_init(rng, tables + wave * (WAVE + 1), base, inc, ro.rng_kind);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): table and cursors visible to the whole wave
 
     const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
@@ -856,7 +881,9 @@ __global__ void __launch_bounds__(256, 4) k_eval_mc(offsim_table t, offsim_rollo
     if (lane == 0) {
         ro.init_cursor[r] = ic;
         ro.cur_slot[r] = slot;
-        if (consumed) {
+        if (consumed && ro.rng_kind == OFFSIM_STREAM_PHILOX) {
+            ro.rng[4 * r + 1] = base.lo + consumed;
+        } else if (consumed) {
             U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
             ro.rng[4 * r + 0] = nb.hi;
             ro.rng[4 * r + 1] = nb.lo;
@@ -1141,6 +1168,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_mc_keys: required output is NULL%s");
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: candidate windows support at most 256 states%s");
+    if (ro->rng_kind != OFFSIM_STREAM_PCG64) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: the compiled-policy scans draw from PCG64 only (use offsim_eval_mc)%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: queue positions, candidate and step counters are 32-bit (N < 2^32)%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_keys: gamma_pow is NULL%s");
     if (ro->R == 0) return OFFSIM_OK;
@@ -1198,6 +1226,7 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_mc_streams: required output is NULL%s");
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: candidate windows support at most 256 states%s");
+    if (ro->rng_kind != OFFSIM_STREAM_PCG64) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: the compiled-policy scans draw from PCG64 only (use offsim_eval_mc)%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
     // positions inside a state's queue travel in 17-bit fields of the request descriptors and as 16-bit local rows (loc)

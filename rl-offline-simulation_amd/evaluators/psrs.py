@@ -86,6 +86,8 @@ class BatchedPSRS:
         sd = seeds_tensor(seeds, dev)
         assert sd.numel() == self.R, "one seed per rollout"
         seed_streams(sd, self.state.rng)
+        self.state.rng_kind = L.STREAM_PCG64
+        self.state._refresh()
         self.state.rewind()
         self._streams = None
         self._perm_lazy = None
@@ -190,9 +192,23 @@ class BatchedPSRS:
             return self.state.perm
         return ((self._loc_buf.to(torch.int64) & 0xFFFF) + self._seg_base()[None, :]).to(torch.int32)
 
-    def set_rejection_seeds(self, seeds):
-        """Replace only the rejection streams (env.rejection_sampling_rng = default_rng(seed), psrs.py:20)."""
-        seed_streams(seeds_tensor(seeds, self.table.device), self.state.rng)
+    def set_rejection_seeds(self, seeds, provider="pcg64"):
+        """Replace only the rejection streams (env.rejection_sampling_rng = ..., psrs.py:20 is a plain attribute).
+        provider = "pcg64": default_rng(seed) -- the reference's numbers.  provider = "philox": rocRAND's Philox4x32-10 through its
+        device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by step / step_single / eval_td
+        and the generic eval_mc (the compiled-policy scans draw from PCG64 only); reset_sampler puts PCG64 back."""
+        sd = seeds_tensor(seeds, self.table.device)
+        assert sd.numel() == self.R, "one seed per rollout"
+        if provider == "pcg64":
+            seed_streams(sd, self.state.rng)
+            self.state.rng_kind = L.STREAM_PCG64
+        elif provider == "philox":
+            self.state.rng.zero_()
+            self.state.rng[:, 0] = sd  # seed, draws consumed, 0, 0
+            self.state.rng_kind = L.STREAM_PHILOX
+        else:
+            raise ValueError(provider)
+        self.state._refresh()
 
     def _orders_for_generic(self):
         """The kernels that take any p_new per step (step, step_single, eval_td, the generic eval_mc) walk the queues through
@@ -283,11 +299,11 @@ class BatchedPSRS:
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
                          trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
-        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256
+        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and self.state.rng_kind == L.STREAM_PCG64
         if fast is None:
             fast = can_fast
         if fast and not can_fast:
-            raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule and <= 256 states")
+            raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule, <= 256 states and the PCG64 stream")
         pkey = self._policy_key(pi_slots) if fast else None  # (once per call: a device tensor is copied to the host for it)
         if fast and not (self._streams is not None and self._streams["key"] == pkey):
             self._derive_streams(pi_slots, key=pkey)  # small jobs: the streams are gathered from the permutations on the spot

@@ -188,12 +188,13 @@ class RolloutState:
         self.perm_stride = 0
         self.init_perm = None
         self.init_stride = 0
+        self.rng_kind = L.STREAM_PCG64
         self._refresh()
 
     def _refresh(self):
         self.c = L.Rollouts(R=self.R, rng=L.ptr(self.rng), cursor=L.ptr(self.cursor), init_cursor=L.ptr(self.init_cursor),
                             cur_slot=L.ptr(self.cur_slot), perm=L.ptr(self.perm), perm_stride=self.perm_stride,
-                            init_perm=L.ptr(self.init_perm), init_stride=self.init_stride)
+                            init_perm=L.ptr(self.init_perm), init_stride=self.init_stride, rng_kind=self.rng_kind)
 
     def set_orders(self, perm, perm_stride, init_perm, init_stride):
         self.perm, self.perm_stride, self.init_perm, self.init_stride = perm, int(perm_stride), init_perm, int(init_stride)

@@ -351,6 +351,49 @@ def main():
     np.savez_compressed(os.path.join(OUT, "td2_iid_2k.npz"), **out)
     print(f"{'td2_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's0_{t}_rows']) for t in ('sched', 'ties', 'ties_sched', 'greedy', 'soft', 'saveq', 'es_sched')]}")
 
+    # ---- 11c. the Philox stream provider (include/offsim.h OFFSIM_STREAM_PHILOX): the reference's own PSRS with
+    # env.rejection_sampling_rng (a plain attribute, psrs.py:20) replaced by an object whose .random() replays rocRAND's
+    # Philox4x32-10 -- restated here from /opt/rocm/include/rocrand/rocrand_philox4x32_10.h (Random123 rounds, key = seed, counter = index
+    # of the group of four 32-bit outputs) and rocrand_uniform.h (two outputs -> (0, 1] double).  Queue orders stay NumPy's (seed).
+    class PhiloxReplay:
+        M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+        def __init__(self, seed):
+            self.key, self.i = (seed & 0xffffffff, (seed >> 32) & 0xffffffff), 0
+
+        def four(self, counter):
+            c = [counter & 0xffffffff, (counter >> 32) & 0xffffffff, 0, 0]
+            k0, k1 = self.key
+            for _ in range(10):
+                m0, m1 = self.M0 * c[0], self.M1 * c[2]
+                c = [((m1 >> 32) ^ c[1] ^ k0) & 0xffffffff, m1 & 0xffffffff, ((m0 >> 32) ^ c[3] ^ k1) & 0xffffffff, m0 & 0xffffffff]
+                k0, k1 = (k0 + self.W0) & 0xffffffff, (k1 + self.W1) & 0xffffffff
+            return c
+
+        def random(self):
+            w = self.four(self.i >> 1)[2 * (self.i & 1): 2 * (self.i & 1) + 2]  # 32-bit outputs 2 i and 2 i + 1
+            self.i += 1
+            return 2.0 ** -53 + float(w[0] | ((w[1] >> 11) << 32)) * 2.0 ** -53
+
+    inp = iid2k
+    out = {("in_" + k): v for k, v in inp.items()}
+    out["seeds"], out["pi"], out["gamma"], out["p_new_step"] = np.array([0, 7, 2 ** 40 + 5], np.int64), pi25, np.float64(0.99), np.full(5, 0.2)
+    out["first_draws"] = np.array([[PhiloxReplay(int(s)).random() for _ in range(1)] + [0.0] * 7 for s in out["seeds"]])
+    for k, s in enumerate(out["seeds"]):
+        g = PhiloxReplay(int(s))
+        out["first_draws"][k] = [g.random() for _ in range(8)]
+    h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+    for s in out["seeds"]:
+        s = int(s)
+        for proto in ("step", "mc"):
+            h.env.reset_sampler(seed=s)
+            h.env.rejection_sampling_rng = PhiloxReplay(s)
+            res = run_step_protocol(h, out["p_new_step"]) if proto == "step" else run_evalmc(h, pi25, 0.99, 10 ** 9)
+            for k, v in res.items():
+                out[f"s{s}_{proto}_{k}"] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "philox_iid_2k.npz"), **out)
+    print(f"{'philox_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's{int(s)}_mc_rows']) for s in out['seeds']]}")
+
     # ---- 12. QueueEvaluator_impl (queue_evaluator.py:90-131): (z, a)-keyed queues, no rejection.  The module imports gym at
     # the top, so only the class (numpy + itertools) is compiled from the reference file, unmodified, in memory.
     import ast

@@ -218,3 +218,61 @@ def test_bench_two_ranks_on_one_device(gpu):
     assert line["n_gpus"] == 2 and line["parity_check"]["ok"]
     assert line["config"]["rollout_tile"] == 256 and line["config"]["queue_orders_resident_bytes_rank0"] > 256 * 6 * 900000
     assert line["rollout_sharded"]["rollouts_per_gpu"] == 128
+
+
+def test_philox_stream_provider_against_the_reference_with_a_replayed_stream(gpu):
+    """OFFSIM_STREAM_PHILOX (rocRAND's Philox4x32-10 device API in the generic kernels): the rows the reference's PSRS serves when its
+    rejection_sampling_rng replays the same stream (tests/golden/philox_iid_2k.npz) -- step protocol through
+    offsim_step_batch, evalMC through offsim_eval_mc; accepted rows, candidates popped per step, Gs and lengths equal."""
+    from rl_offline_simulation_amd import _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    d = load("philox_iid_2k")
+    table = TransitionTable(d["in_z"], d["in_a"], d["in_r"], d["in_z_next"], d["in_done"], d["in_p_log"], d["in_t0"], device=gpu)
+    seeds = [int(s) for s in d["seeds"]]
+    R = len(seeds)
+    env = BatchedPSRS(table, R)
+    # evalMC
+    env.reset_sampler(seeds)
+    env.set_rejection_seeds(seeds, provider="philox")
+    cap = table.N + 1
+    o = env.eval_mc(table.policy_slots(d["pi"]), float(d["gamma"]), ep_cap=table.N0 + 1, trace_cap=cap)
+    torch.cuda.synchronize()
+    with pytest.raises(L.OffsimError):
+        env.eval_mc(table.policy_slots(d["pi"]), float(d["gamma"]), fast=True)
+    for i, s in enumerate(seeds):
+        n = int(o["steps"][i])
+        assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), d[f"s{s}_mc_rows"])
+        assert np.array_equal(o["trace_pop"][i, :n].cpu().numpy(), d[f"s{s}_mc_popped"][:n])
+        ne, nl = int(o["n_ep"][i]), int(o["n_len"][i])
+        assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), d[f"s{s}_mc_Gs"])
+        assert np.array_equal(o["ep_len"][i, :nl].cpu().numpy(), d[f"s{s}_mc_lengths"])
+    # the step protocol of the reference's tests/test_psrs.py:25-31 (one fixed p_new, reset on done), all seeds side by side
+    env.reset_sampler(seeds)
+    env.set_rejection_seeds(seeds, provider="philox")
+    first = env.reset().cpu().numpy()
+    p = np.tile(d["p_new_step"], (R, 1))
+    rows = [[] for _ in seeds]
+    pops = [[] for _ in seeds]
+    alive = first >= 0
+    for it in range(4 * table.N):
+        if not alive.any():
+            break
+        row, status, popped = (x.cpu().numpy() for x in env.step(p))
+        again = np.zeros(R, bool)
+        for i in range(R):
+            if not alive[i]:
+                continue
+            pops[i].append(int(popped[i]))
+            rows[i].append(int(row[i]))
+            if status[i] != L.ST_OK:
+                alive[i] = False
+            elif d["in_done"][row[i]]:
+                again[i] = True
+        if again.any():
+            nxt = env.reset(mask=torch.from_numpy(again).to(gpu)).cpu().numpy()
+            alive &= ~(again & (nxt < 0))
+        env.set_state(torch.full((R,), -1, dtype=torch.int32), mask=torch.from_numpy(~alive).to(gpu)) if (~alive).any() else None
+    for i, s in enumerate(seeds):
+        assert rows[i] == [int(x) for x in d[f"s{s}_step_rows"]], s
+        assert pops[i] == [int(x) for x in d[f"s{s}_step_popped"]], s
