@@ -172,6 +172,16 @@ typedef struct {
 int offsim_vector_gather(const int32_t *row, const int32_t *status, const uint8_t *mask, int32_t R, const offsim_column *cols,
                          int32_t n_cols, uint8_t *alive, void *stream);
 
+/* One driver iteration of a batched evaluator in one launch (VectorPSRS.step_and_reset; the loop of
+ * examples/cartpole/psrs_from_expert_heuristic.py:59-80 vectorised over environments): PSRS.step(p_new[r]) as offsim_step_batch
+ * (advance = 1), then step_cols gathered from the served caller-buffer row into row r of their destinations (zero_if_not_ok columns
+ * are cleared where nothing was served), then -- where the served transition ended its episode -- PSRS.reset (offsim_env_reset) and
+ * reset_cols gathered from the initial row (typically the observation, written over the next observation).  alive[r] (optional, in/out)
+ * is cleared where the step returned None or the reset found the init queue empty.  out_row / out_status (optional) as offsim_step_batch. */
+int offsim_vector_step(const offsim_table *t, offsim_rollouts *ro, const void *p_new, int32_t prob_mode, int32_t reject_mode,
+                       const offsim_column *step_cols, int32_t n_step_cols, const offsim_column *reset_cols, int32_t n_reset_cols,
+                       uint8_t *alive, int32_t *out_row, int32_t *out_status, void *stream);
+
 /* evalMC_psrs(env, n_episodes, pi, gamma) (psrs.py:241-271) for all rollouts in one launch.
  * pi [n_slots,nA] (row s = policy in state slot s), same dtype rule as p_new.
  * gamma_pow [n_gamma_pow] f64 holds gamma**t as the host computes it (Python float ** int == libm pow); Gs are bit-exact

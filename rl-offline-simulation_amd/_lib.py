@@ -73,6 +73,7 @@ SIGNATURES = {
     "offsim_env_reset": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _vp, _vp]),
     "offsim_env_set_state": (C.c_int, [C.POINTER(Rollouts), _vp, _vp, _vp]),
     "offsim_vector_gather": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp]),
+    "offsim_vector_step": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "offsim_step_batch": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, _i32, C.c_double, _vp, _i64, _i64,
                                  C.POINTER(EvalMCOut), _vp]),

@@ -975,6 +975,123 @@ extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const 
     return OFFSIM_OK;
 }
 
+// ---- one driver iteration of the batched evaluator in ONE launch (VectorPSRS.step_and_reset): PSRS.step with the environment's own
+// p_new (per_state_rejection.py:85-95), the payload of the served row (action, next observation, reward, done -> the caller's step
+// buffers), and for the environments whose episode ended PSRS.reset (psrs.py:32-37) with the initial observation written over the next
+// one.  One wavefront per environment, as k_step_batch; the lanes share the copies.
+__device__ __forceinline__ void vec_copy_cols(const VecCols &cols, int n_cols, int64_t src_row, int64_t dst_row, bool ok, int lane) {
+    for (int c = 0; c < n_cols; c++) {
+        const int64_t nb = cols.c[c].row_bytes;
+        unsigned char *d = (unsigned char *)cols.c[c].dst + dst_row * nb;
+        if (ok) {
+            const unsigned char *sp = (const unsigned char *)cols.c[c].src + src_row * nb;
+            if (((nb | (int64_t)(uintptr_t)sp | (int64_t)(uintptr_t)d) & 3) == 0) {
+                for (int64_t b = 4 * lane; b < nb; b += 4 * WAVE) *(uint32_t *)(d + b) = *(const uint32_t *)(sp + b);
+            } else {
+                for (int64_t b = lane; b < nb; b += WAVE) d[b] = sp[b];
+            }
+        } else if (cols.c[c].zero_if_not_ok) {
+            for (int64_t b = lane; b < nb; b += WAVE) d[b] = 0;
+        }
+    }
+}
+
+template <typename PL, typename PROB>
+__global__ void __launch_bounds__(256) k_vector_step(offsim_table t, offsim_rollouts ro, const PROB *__restrict__ p_new, int reject_mode,
+                                                     VecCols step_cols, int n_step, VecCols reset_cols, int n_reset,
+                                                     uint8_t *__restrict__ alive, int32_t *__restrict__ out_row, int32_t *__restrict__ out_status) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+    const int r = blockIdx.x * (blockDim.x / WAVE) + wave;
+    if (r >= ro.R) return;
+    const int slot = ro.cur_slot[r];
+    if (slot < 0) {  // (no current state: reset() returned None earlier, or the environment was never reset)
+        if (lane == 0) {
+            if (out_row) out_row[r] = -1;
+            if (out_status) out_status[r] = OFFSIM_ST_INACTIVE;
+            if (alive) alive[r] = 0;
+        }
+        vec_copy_cols(step_cols, n_step, 0, r, false, lane);
+        return;
+    }
+    Jump *table = (Jump *)lds_raw + wave * (WAVE + 1);
+    WaveRng rng;
+    const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]), inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+    rng.kind = ro.rng_kind;
+    if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc, ro.rng_kind);
+    uint64_t consumed = 0;
+    const uint32_t *perm_row = ro.perm ? ro.perm + (int64_t)r * ro.perm_stride : nullptr;
+    const StepResult s = psrs_step<PL, PROB>(t, t.seg_off, perm_row, slot, ro.cursor + (int64_t)r * t.n_slots, p_new + (int64_t)r * t.nA,
+                                             reject_mode, 0u, rng, consumed);
+    const bool ok = s.status == OFFSIM_ST_OK;
+    const int32_t row = ok ? t.orig_idx[s.g] : -1;
+    vec_copy_cols(step_cols, n_step, row, r, ok, lane);
+    bool live = ok;
+    int32_t next_slot = ok ? s.z_next : slot;  // (a None step leaves the state where it was, psrs.py:44-45)
+    if (ok && s.done) {  // the caller's loop: `if done: obs = env.reset()` (examples/cartpole/psrs_from_expert_heuristic.py:76-80)
+        const uint32_t ic = ro.init_cursor[r];
+        if ((int64_t)ic >= t.N0) {
+            next_slot = -1;
+            live = false;
+        } else {
+            const uint32_t k = ro.init_perm ? ro.init_perm[(int64_t)r * ro.init_stride + ic] : ic;
+            if (lane == 0) ro.init_cursor[r] = ic + 1;
+            next_slot = t.init_slot[k];
+            vec_copy_cols(reset_cols, n_reset, t.init_orig[k], r, true, lane);
+        }
+    }
+    if (lane == 0) {
+        if (consumed && ro.rng_kind == OFFSIM_STREAM_PHILOX) {
+            ro.rng[4 * r + 1] = base.lo + consumed;
+        } else if (consumed) {
+            const U128 nb = pcg_apply(pcg_jump(inc, consumed), base);
+            ro.rng[4 * r + 0] = nb.hi;
+            ro.rng[4 * r + 1] = nb.lo;
+        }
+        ro.cur_slot[r] = next_slot;
+        if (alive) alive[r] = (uint8_t)(alive[r] && live);
+        if (out_row) out_row[r] = row;
+        if (out_status) out_status[r] = s.status;
+    }
+}
+
+extern "C" int offsim_vector_step(const offsim_table *t, offsim_rollouts *ro, const void *p_new, int32_t prob_mode, int32_t reject_mode,
+                                  const offsim_column *step_cols, int32_t n_step_cols, const offsim_column *reset_cols, int32_t n_reset_cols,
+                                  uint8_t *alive, int32_t *out_row, int32_t *out_status, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R < 0 || !p_new || n_step_cols < 0 || n_step_cols > 8 || n_reset_cols < 0 || n_reset_cols > 8 ||
+        (n_step_cols > 0 && !step_cols) || (n_reset_cols > 0 && !reset_cols))
+        return fail(OFFSIM_EINVAL, "vector_step: bad argument%s");
+    if (prob_mode == OFFSIM_PROB_F32 && t->plog_dtype != OFFSIM_F32) return fail(OFFSIM_EINVAL, "vector_step: OFFSIM_PROB_F32 needs an f32 p_log%s");
+    VecCols sc, rcols;
+    memset(&sc, 0, sizeof(sc));
+    memset(&rcols, 0, sizeof(rcols));
+    for (int c = 0; c < n_step_cols; c++) {
+        if (!step_cols[c].src || !step_cols[c].dst || step_cols[c].row_bytes <= 0) return fail(OFFSIM_EINVAL, "vector_step: bad column%s");
+        sc.c[c] = step_cols[c];
+    }
+    for (int c = 0; c < n_reset_cols; c++) {
+        if (!reset_cols[c].src || !reset_cols[c].dst || reset_cols[c].row_bytes <= 0) return fail(OFFSIM_EINVAL, "vector_step: bad column%s");
+        rcols.c[c] = reset_cols[c];
+    }
+    if (ro->R == 0) return OFFSIM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int waves = 4;
+    dim3 grid((ro->R + waves - 1) / waves), block(waves * WAVE);
+    const size_t lds = (size_t)waves * (WAVE + 1) * sizeof(Jump);
+#define LAUNCH_VS(PL, PROB)                                                                                                         \
+    hipLaunchKernelGGL((k_vector_step<PL, PROB>), grid, block, lds, st, *t, *ro, (const PROB *)p_new, reject_mode, sc, n_step_cols, rcols, \
+                       n_reset_cols, alive, out_row, out_status)
+    if (prob_mode == OFFSIM_PROB_F32) LAUNCH_VS(float, float);
+    else if (t->plog_dtype == OFFSIM_F32) LAUNCH_VS(float, double);
+    else if (t->plog_dtype == OFFSIM_F64) LAUNCH_VS(double, double);
+    else LAUNCH_VS(__half, double);
+#undef LAUNCH_VS
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 // ---- PSRS_Exo.step (psrs.py:99-117): two queue families, endogenous state s and exogenous state x.  Every candidate
 // pops the head of BOTH s_queues[s] and x_queues[x]; the rejection test reads the s-row (a, p_log); the accepted
 // candidate's s-row gives (r, s', done) and its x-row gives x'.  Lane k tests candidate k of both queues with draw c+k.

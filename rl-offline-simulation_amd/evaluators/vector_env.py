@@ -17,6 +17,8 @@ synchronisation per call.  `obs` and `alive` are updated in place, and a call is
 stream, so a whole driver iteration (policy forward -> step_dist_batch -> reset of the finished environments) can be
 captured once in a HIP graph and replayed (`torch.cuda.graph`, see `graph_iteration`): the loop is launch-bound otherwise.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -107,8 +109,29 @@ class VectorPSRS:
                                               L.ptr(self.alive), L.stream_ptr()))
         return self.action, self.obs, self.reward, self.done, self.alive
 
-    def graph_iteration(self, dist_fn, warmup=3):
-        """Capture one driver iteration in a HIP graph: probs = dist_fn(self.obs); step_dist_batch(probs); reset(mask=done).
+    def step_and_reset(self, action_dists):
+        """step_dist_batch followed by reset(mask=done) -- a whole driver iteration of the environments -- as ONE launch
+        (offsim_vector_step).  Returns (action, obs, reward, done, alive): obs is the next observation, or the initial observation of
+        the next episode where `done`; the same buffers as step_dist_batch's."""
+        if isinstance(action_dists, Distribution):
+            action_dists = action_dists.probs
+        env, t = self.env, self.table
+        env._orders_for_generic()
+        p = action_dists if isinstance(action_dists, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(action_dists))
+        f32 = p.dtype == torch.float32 and t.p_log.dtype == torch.float32
+        p = p.to(device=t.device, dtype=torch.float32 if f32 else torch.float64).reshape(self.num_envs, t.nA).contiguous()
+        L.check(L.load().offsim_vector_step(C.byref(t.c), C.byref(env.state.c), L.ptr(p), L.PROB_F32 if f32 else L.PROB_F64, env.reject_mode,
+                                            self._cols_step, len(self._cols_step), self._cols_reset, len(self._cols_reset), L.ptr(self.alive),
+                                            L.ptr(env._row), L.ptr(env._status), L.stream_ptr()))
+        if self.strict and bool((env._status == L.ST_KEYERROR).any()):
+            k = int(torch.nonzero(env._status == L.ST_KEYERROR)[0])
+            raise KeyError(self.table.z_of(int(env.state.cur_slot[k])))
+        self._keep = p
+        return self.action, self.obs, self.reward, self.done, self.alive
+
+    def graph_iteration(self, dist_fn, warmup=3, fused=True):
+        """Capture one driver iteration in a HIP graph: probs = dist_fn(self.obs); step_and_reset(probs) (fused=False: the four
+        launches of step_dist_batch(probs); reset(mask=done)).
         Returns (graph, (action, reward, done)): every graph.replay() advances all environments by one step and leaves the
         step's outputs in those three tensors (and in self.obs / self.alive).  `warmup` eager iterations run first on a side
         stream (PyTorch's capture recipe; they are real steps of the environments).  strict must be False."""
@@ -116,6 +139,9 @@ class VectorPSRS:
             raise ValueError("graph capture needs strict=False (the KeyError check synchronises with the host)")
 
         def iteration():
+            if fused:  # one launch for the environments' whole iteration
+                a, _, r, done, _ = self.step_and_reset(dist_fn(self.obs))
+                return a, r, done
             a, _, r, done, _ = self.step_dist_batch(dist_fn(self.obs))
             self.reset(mask=done)
             return a, r, done

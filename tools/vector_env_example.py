@@ -23,6 +23,9 @@ env.reset_sampler(np.arange(R))
 obs, alive = env.reset()
 use_graph = os.environ.get("OFFSIM_EXAMPLE_GRAPH", "1") != "0"
 dist = lambda o: torch.softmax(policy(o), dim=1).to(torch.float64)
+if os.environ.get("OFFSIM_EXAMPLE_POLICY") == "fixed":  # the environments' share of an iteration: no network, one fixed distribution per environment
+    fixed_probs = torch.full((R, 2), 0.5, dtype=torch.float64, device=dev)
+    dist = lambda o: fixed_probs
 n_calls = 3000
 torch.cuda.synchronize()
 if use_graph:  # one driver iteration captured in a HIP graph: the eager loop is bound by its ~15 launches per iteration
@@ -48,7 +51,7 @@ else:
     el = time.perf_counter() - t0
 live_frac = float(env.alive.float().mean())
 import json
-print(json.dumps({"tool": "vector_env_example", "mode": "hip graph replay" if use_graph else "eager", "environments": R, "log_transitions": N,
+print(json.dumps({"tool": "vector_env_example", "mode": "hip graph replay" if use_graph else "eager", "policy": os.environ.get("OFFSIM_EXAMPLE_POLICY", "4-64-64-2 MLP + softmax (8 torch kernels)"), "environments": R, "log_transitions": N,
                   "calls": calls, "us_per_call": el / calls * 1e6, "simulated_steps_per_s_lower_bound": R * calls * live_frac / el,
                   "alive_fraction_at_end": live_frac,
                   "reference": "single-environment Python loop: ~1e5 steps/s at N = 5e4, ~2e4 at N = 1e6 (BASELINE.md)"}))
