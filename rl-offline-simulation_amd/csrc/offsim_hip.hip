@@ -1510,6 +1510,30 @@ static int launch_mlp_mfma(const XT *x, int64_t N, int dO, const float *W1, cons
                            int nZ, int32_t *out_z, float *out_logits, hipStream_t st) {
     const int HT = (H + 31) / 32, ZT = (nZ + 31) / 32;
     const int dOp = (dO + 1) & ~1;
+    {   // weights in registers (encode_mfma.hpp, second kernel): the observation widths of the reference's configurations, hidden layer
+        // <= 64, rows 16-byte aligned where they are read as 16-byte words
+        const bool al = ((uintptr_t)x & 15) == 0;
+        int64_t groups = (N + 31) / 32;
+        unsigned nb = (unsigned)((groups + 3) / 4);
+        if (nb > 256) nb = 256;  // one workgroup (a wavefront per SIMD) per CU
+        if (nb < 1) nb = 1;
+#define LAUNCH_REG(DOc, HTc, ZTc, WPEc)                                                                                                \
+    do {                                                                                                                               \
+        hipLaunchKernelGGL((k_encode_mlp_mfma_reg<XT, DOc, HTc, ZTc, WPEc>), dim3(nb * WPEc), dim3(256), 0, st, x, N, W1, b1, H, W2, b2, nZ, out_z, \
+                           out_logits);                                                                                                \
+        LAUNCH_CHECK();                                                                                                                \
+        return OFFSIM_OK;                                                                                                              \
+    } while (0)
+        if (HT == 2 && al) {  // (narrow observations: a tile is short, two wavefronts per SIMD fill each other's gaps)
+            if (dO == 128 && ZT == 2) LAUNCH_REG(128, 2, 2, 1);
+            if (dO == 128 && ZT == 1) LAUNCH_REG(128, 2, 1, 1);
+            if (dO == 2 && ZT == 1) LAUNCH_REG(2, 2, 1, 2);
+            if (dO == 2 && ZT == 2) LAUNCH_REG(2, 2, 2, 2);
+            if (dO == 4 && ZT == 1) LAUNCH_REG(4, 2, 1, 2);
+            if (dO == 4 && ZT == 2) LAUNCH_REG(4, 2, 2, 2);
+        }
+#undef LAUNCH_REG
+    }
     size_t lds = sizeof(float) * ((size_t)HT * 32 * (dOp + 1) + (size_t)ZT * 32 * (HT * 32 + 1) + HT * 32 + ZT * 32);
     if (lds > 160 * 1024) return fail(OFFSIM_EUNSUPPORTED, "encode_mlp: weights exceed LDS%s");
     int64_t groups = (N + 31) / 32;
