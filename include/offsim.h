@@ -305,30 +305,38 @@ int offsim_async_faults(void);
 int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
 
 /* ---- headline scan on per-rollout candidate streams ------------------------------------------------------------
- * For a fixed tabular policy the scan needs, per candidate, only the 32-bit digest of its compiled key (top 21 bits of
- * the threshold T, done, z_next) -- and per ACCEPTED candidate the row (for its reward).  Gathering digests through a
+ * For a fixed tabular policy the scan needs, per candidate, only a 32-bit digest of its compiled key (the top bits of the
+ * threshold T, done, z_next) -- and per ACCEPTED candidate the row (for its reward).  Gathering digests through a
  * per-rollout permutation moves a 64-byte sector per 4-byte digest, so the sampler reset can instead lay the queue
  * orders out as two streams per rollout, both indexed like `perm` (seg_off[s] + k = k-th element of state s's queue):
  *   dig [n, N] u32   digest of the candidate at that queue position      -> read sequentially by the scan
- *   loc [n, N] u16   its row inside the state's segment (grouped row - seg_off[s]); needs segments <= 65536 rows
- * offsim_compile_digests: dig32[g] = high dword of the compiled key of grouped row g (offsim_compile_policy's keys).
+ *   loc [n, N] u16   its row inside the state's segment (grouped row - seg_off[s]), low 16 bits
+ * 4 + 2 bytes per queue position and rollout in either of two layouts of the digest (offsim_streams.format):
+ *   OFFSIM_STREAMS_A   [T >> 32 : 21 | done : 1 | z_next : 10] = the high dword of the compiled key; loc is the whole local row:
+ *                      every state has at most 65536 rows;
+ *   OFFSIM_STREAMS_B   [T >> 37 : 16 | hi[6:2] : 5 | done : 1 | hi[1:0] : 2 | z_next : 8], hi = bits 16..22 of the local row:
+ *                      states of up to 2^23 rows, at most 256 states.  (The coarser threshold only widens the band of draws that
+ *                      are decided by the exact 53-bit look; results are the same bit for bit.)
+ * offsim_compile_digests: dig32[g] = the digest of grouped row g in `format`, local-row bits zero (from offsim_compile_policy's keys).
  * offsim_shuffle_queues_keys: PSRS.reset_sampler's shuffles (psrs.py:22-23,29-30; same orders as offsim_shuffle_queues,
- *   bit for bit) written as those streams; init_perm_out as in offsim_shuffle_queues.  OFFSIM_EUNSUPPORTED if a state
- *   has more than 65536 rows (use offsim_shuffle_queues + offsim_eval_mc_keys).
+ *   bit for bit) written as those streams; init_perm_out as in offsim_shuffle_queues.  States of more than 65536 rows need
+ *   format B (OFFSIM_EUNSUPPORTED otherwise): their chains are shuffled in place in dig_out and converted afterwards.
  * offsim_eval_mc_streams: evalMC_psrs (psrs.py:241-271) from the streams; same outputs, bit for bit, as offsim_eval_mc /
- *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide 21-bit digest ties
+ *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide digest ties
  *   exactly.  Strides are in elements; stride 0 = one order shared by all rollouts; loc == NULL = queues in table order
- *   (dig = dig32 itself, stride 0).  ro->perm / perm_stride are ignored; ro->init_perm is used as everywhere else.
- *   n_slots <= 256. * offsim_eval_mc_streams returns OFFSIM_EUNSUPPORTED unless offsim_table.max_seg is set and <= 65536 (with or without `loc`):
- * queue positions travel in 17-bit descriptor fields. */
+ *   (dig = dig32 itself, stride 0; format A).  ro->perm / perm_stride are ignored; ro->init_perm is used as everywhere else.
+ *   n_slots <= 256; offsim_table.max_seg must be set: <= 65536 for format A, <= 2^23 for format B (OFFSIM_EUNSUPPORTED otherwise). */
+#define OFFSIM_STREAMS_A 0
+#define OFFSIM_STREAMS_B 1
 typedef struct offsim_streams {
     const uint32_t *dig;
     int64_t dig_stride;
     const uint16_t *loc;
     int64_t loc_stride;
+    int32_t format; /* OFFSIM_STREAMS_* */
 } offsim_streams;
-int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, uint32_t *dig32_out, void *stream);
-int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32,
+int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, int32_t format, uint32_t *dig32_out, void *stream);
+int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
                                uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream);
 int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro, const offsim_streams *sm, const uint64_t *keys,
                            double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,

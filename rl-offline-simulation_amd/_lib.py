@@ -14,6 +14,7 @@ OK = 0
 F32, F64, F16 = 0, 1, 2
 REJECT_DEFAULT, REJECT_NEVER = 0, 1
 STREAM_PCG64, STREAM_PHILOX = 0, 1
+STREAMS_A, STREAMS_B = 0, 1
 PROB_F64, PROB_F32 = 0, 1
 ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE, ST_PROTOCOL = 0, 1, 2, 3, 4, 5
 
@@ -42,7 +43,7 @@ class EvalMCOut(C.Structure):
 
 class Streams(C.Structure):
     """struct offsim_streams"""
-    _fields_ = [("dig", _vp), ("dig_stride", _i64), ("loc", _vp), ("loc_stride", _i64)]
+    _fields_ = [("dig", _vp), ("dig_stride", _i64), ("loc", _vp), ("loc_stride", _i64), ("format", _i32)]
 
 
 class Column(C.Structure):
@@ -83,8 +84,8 @@ SIGNATURES = {
                                  C.POINTER(EvalMCOut), C.POINTER(TD), _vp]),
     "offsim_compile_policy": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
     "offsim_eval_mc_keys_kernel": (C.c_char_p, [_i32, _i32]),
-    "offsim_compile_digests": (C.c_int, [C.POINTER(Table), _vp, _vp, _vp]),
-    "offsim_shuffle_queues_keys": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "offsim_compile_digests": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp]),
+    "offsim_shuffle_queues_keys": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "offsim_eval_mc_streams": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), C.POINTER(Streams), _vp, C.c_double, _vp, _i64, _i64,
                                          C.POINTER(EvalMCOut), _vp]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,

@@ -337,15 +337,39 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
     return launch_shuffle(t, seeds, n_perm, perm_out, init_perm_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32,
+// Keyed form of the chains that do not fit LDS (states of more than 65536 rows, stream format B): the global-memory variant has shuffled
+// grouped-row indices in place in the state's slice of dig_out; every position becomes {digest | local-row bits 16.., local-row low half}.
+__global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ seg_off, int64_t N, const uint32_t *__restrict__ dig32,
+                                                  uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out) {
+    const uint32_t s = blockIdx.y, r = blockIdx.z;
+    const uint32_t beg = seg_off[s], len = seg_off[s + 1] - beg;
+    if (len <= SHUF_CAP16) return;
+    for (uint32_t k = blockIdx.x * 1024u + threadIdx.x; k < len && k < (blockIdx.x + 1u) * 1024u; k += 256u) {
+        const int64_t p = (int64_t)r * N + beg + k;
+        const uint32_t row = dig_out[p], loc = row - beg, h = loc >> 16;
+        dig_out[p] = dig32[row] | ((h & 3u) << 8) | ((h >> 2) << 11);
+        loc_out[p] = (uint16_t)loc;
+    }
+}
+
+extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
                                           uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream) {
     if (!t || !seeds || n_perm < 0 || !init_perm_out || (t->N > 0 && (!dig32 || !dig_out || !loc_out)))
         return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad argument%s");
+    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad format%s");
     if (t->max_seg <= 0 && t->N > 0) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: offsim_table.max_seg must be set%s");
-    if (t->max_seg > (int64_t)SHUF_CAP16)
-        return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows (16-bit local rows); use offsim_shuffle_queues%s");
+    const bool big = t->max_seg > (int64_t)SHUF_CAP16;
+    if (big && format != OFFSIM_STREAMS_B)
+        return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows: stream format B (or offsim_shuffle_queues)%s");
+    if (big && (t->max_seg > (1ll << 23) || t->n_slots > 256)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 256 states%s");
     if (n_perm == 0) return OFFSIM_OK;
-    return launch_shuffle(t, seeds, n_perm, nullptr, init_perm_out, dig32, dig_out, loc_out, (hipStream_t)stream);
+    int rc = launch_shuffle(t, seeds, n_perm, big ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, (hipStream_t)stream);
+    if (rc || !big) return rc;
+    if (n_perm > 65535) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: more than 65535 orders of a big-segment table per call%s");
+    hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)n_perm), dim3(256), 0, (hipStream_t)stream,
+                       t->seg_off, t->N, dig32, dig_out, loc_out);
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1320,16 +1344,21 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
 // ------------------------------------------------------------------------------------------------
 #include "scan_rows.hpp"
 
-__global__ void k_key_digests(const uint64_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ out) {
+__global__ void k_key_digests(const uint64_t *__restrict__ keys, int64_t N, int format, uint32_t *__restrict__ out) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < N) out[g] = (uint32_t)(keys[g] >> 32);
+    if (g >= N) return;
+    const uint32_t hi = (uint32_t)(keys[g] >> 32);  // [T >> 32 : 21 | done | z_next : 10]
+    out[g] = format == OFFSIM_STREAMS_B ? ((hi >> 16) << 16) | (hi & 0x400u) | (hi & 0xffu) : hi;
 }
-extern "C" int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, uint32_t *dig32_out, void *stream) {
+
+extern "C" int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, int32_t format, uint32_t *dig32_out, void *stream) {
     int rc = check_table(t);
     if (rc) return rc;
     if (t->N > 0 && (!keys || !dig32_out)) return fail(OFFSIM_EINVAL, "compile_digests: bad argument%s");
+    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "compile_digests: bad format%s");
+    if (format == OFFSIM_STREAMS_B && t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format B holds 8-bit states%s");
     if (t->N == 0) return OFFSIM_OK;
-    hipLaunchKernelGGL(k_key_digests, dim3((unsigned)((t->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, t->N, dig32_out);
+    hipLaunchKernelGGL(k_key_digests, dim3((unsigned)((t->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, t->N, format, dig32_out);
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }
@@ -1347,8 +1376,10 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
     // positions inside a state's queue travel in 17-bit fields of the request descriptors and as 16-bit local rows (loc)
-    if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > 65536))
-        return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (use offsim_eval_mc_keys)%s");
+    if (sm->format != OFFSIM_STREAMS_A && sm->format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "eval_mc_streams: bad stream format%s");
+    if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > (sm->format == OFFSIM_STREAMS_B ? (1ll << 23) : 65536ll)))
+        return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (format A) / 2^23 (format B)%s");
+    if (sm->format == OFFSIM_STREAMS_B && !sm->loc) return fail(OFFSIM_EINVAL, "eval_mc_streams: format B needs the loc stream%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool trace = out->trace_row || out->trace_pop;
@@ -1363,19 +1394,22 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
-    if (trace) {
-        HIP_TRY(allow_big_lds((k_eval_mc_rows<true, false>), 160 * 1024));
-        hipLaunchKernelGGL((k_eval_mc_rows<true, false>), grid, dim3((unsigned)(waves * 64)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
-    } else if (!helper) {
-        HIP_TRY(allow_big_lds((k_eval_mc_rows<false, false>), 160 * 1024));
-        hipLaunchKernelGGL((k_eval_mc_rows<false, false>), grid, dim3((unsigned)(waves * 64)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
-    } else {  // a helper wavefront per chain wavefront
-        HIP_TRY(allow_big_lds((k_eval_mc_rows<false, true>), 160 * 1024));
-        hipLaunchKernelGGL((k_eval_mc_rows<false, true>), grid, dim3((unsigned)(waves * 128)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow,
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region);
+#define LAUNCH_ROWS(TR, HL, FMT, THREADS)                                                                                          \
+    do {                                                                                                                           \
+        HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT>), 160 * 1024));                                                          \
+        hipLaunchKernelGGL((k_eval_mc_rows<TR, HL, FMT>), grid, dim3((unsigned)(THREADS)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, \
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region);                                                    \
+    } while (0)
+    if (sm->format == OFFSIM_STREAMS_B) {
+        if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_B, waves * 64);
+        else if (!helper) LAUNCH_ROWS(false, false, OFFSIM_STREAMS_B, waves * 64);
+        else LAUNCH_ROWS(false, true, OFFSIM_STREAMS_B, waves * 128);  // a helper wavefront per chain wavefront
+    } else {
+        if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_A, waves * 64);
+        else if (!helper) LAUNCH_ROWS(false, false, OFFSIM_STREAMS_A, waves * 64);
+        else LAUNCH_ROWS(false, true, OFFSIM_STREAMS_A, waves * 128);
     }
+#undef LAUNCH_ROWS
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }

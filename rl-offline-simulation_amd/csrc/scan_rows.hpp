@@ -55,8 +55,9 @@ namespace offsim {
 #define RO_RING 0u       // 256 draws, k21 << 11 | 0x7ff: a tick (16 looks of <= 8 candidates) never runs out, so the chain loop does not check
 #define RO_INIT 1024u    // ring of 32 upcoming initial states (slot or -1), entry k of the queue at (k - first) & 31
 #define RO_LOG 1152u     // 16 step-log words: state left | done << 10 | candidates consumed (rows_log_k)
-#define RO_LOG2 1280u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
-#define RO_SYNC 1408u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront
+#define RO_LOG2 1216u    // second log buffer (HELPER: the chain fills one while the helper wavefront reads the other)
+#define RO_SYNC 1280u    // HELPER: hand-off words between a rollout's chain wavefront and its helper wavefront (32 B), scratch words (64 B at +64)
+#define RO_LOGH 1408u    // 2 x 16 halfwords beside the step logs: the high bits of the accepted candidate's local row (stream format B, exact-path steps)
 enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20, SY_N1 = 24, SY_REQ = 28 };  // byte offsets in RO_SYNC
 #define ROWS_LIF 26u      // the key's lane field: (lane + 1) << 26, so that byte 3 of a key = 4 x candidates consumed
 // step-log word: bits 0..9 state left, bit 10 done, and the candidates the step consumed -- 1..8 in bits 26..29 (what the
@@ -66,7 +67,7 @@ enum { SY_TICK = 0, SY_HTICK = 4, SY_C = 8, SY_GEN = 12, SY_FIN = 16, SY_N0 = 20
 __device__ __forceinline__ uint32_t rows_log_word(uint32_t s, uint32_t done_bit, uint32_t k) { return s | done_bit | (k << 11) | 0x80000000u; }
 __device__ __forceinline__ uint32_t rows_log_k(uint32_t e) { return (e >> 31) ? ((e >> 11) & 0xfffffu) : (e >> 26); }
 #define ROWS_SPIN_LIMIT (1u << 22)  // polls (with s_sleep) before a hand-off wait gives up: ~2 s, never reached unless the protocol is broken
-#define RO_WIN 1536u     // n_slots x 8 window entries, then cons[n_slots] u32, land[n_slots] u32, claim[n_slots] u8
+#define RO_WIN 1472u     // n_slots x 8 window entries, then cons[n_slots] u32, land[n_slots] u32, claim[n_slots] u8
 
 typedef __attribute__((address_space(3))) volatile uint32_t ldsv_u32;
 typedef __attribute__((address_space(3))) volatile scan_u32x2 ldsv_u32x2;
@@ -77,13 +78,21 @@ typedef __attribute__((address_space(3))) volatile scan_u32x4 ldsv_u32x4;
 #define LV64(a) (*(ldsv_u32x2 *)(a))
 #define LV128(a) (*(ldsv_u32x4 *)(a))
 typedef __attribute__((address_space(3))) volatile uint8_t ldsv_u8;
+typedef __attribute__((address_space(3))) volatile uint16_t ldsv_u16;
+#define LV16(a) (*(ldsv_u16 *)(a))
+__device__ __forceinline__ void lds_w16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t lds_r16(uint32_t a) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
 #define LV8(a) (*(ldsv_u8 *)(a))
 // entries a head-aligned window row holds (the non-empty ones come first)
 __device__ __forceinline__ uint32_t rows_held(scan_u32x4 h0, scan_u32x4 h1) {
     return (h0.x != 0u) + (h0.y != 0u) + (h0.z != 0u) + (h0.w != 0u) + (h1.x != 0u) + (h1.y != 0u) + (h1.z != 0u) + (h1.w != 0u);
 }
 
-__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 41u + 1023u) & ~1023u; }  // 8 KiB at 162 states
+__host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 41u + 1023u) & ~1023u; }  // 8 KiB up to 164 states
 
 // Per-wavefront landing area of the tick's global loads.  They are issued as LDS-DMA (global_load_lds_dword: no VGPR
 // destination, lane l's dword lands at slot base + 4 l) from inline asm, so that the compiler neither sees a pending result
@@ -92,8 +101,8 @@ __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { ret
 // (the two request areas hold FOUR dwords per lane each, lane l's at base + 16 l: one global_load_lds_dwordx4 fills an area)
 enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */, DS_LOC = 8,
        DS_GP = 9 /* four slots: the discount factor of every lane's step (and the table entry behind it) */, DS_RLO = 13, DS_RHI,
-       DS_PROD /* two slots: 16 products per row */, DS_RQD = 17 /* the request each lane made (position | state << 17 | entries << 27) */,
-       DS_SLOTS = 18 };
+       DS_PROD /* two slots: 16 products per row */, DS_RQD = 17 /* the request each lane made: position | entries << 28 */,
+       DS_RQS = 18 /* ... and its state */, DS_SLOTS = 19 };
 #ifndef ROWS_RQ_MAX
 #define ROWS_RQ_MAX 8u  // entries a top-up asks for at most (4: the second request area stays unused)
 #endif
@@ -104,7 +113,22 @@ enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB
 // below the bias -- a candidate that is never a CLEAR accept -- becomes ROWS_NEVER, which no draw is <= (a ring entry's low
 // eleven bits are all set, a payload's never are) and which still lies within the exact look's band of every draw it could accept.
 #define ROWS_NEVER 0x200u
-__device__ __forceinline__ uint32_t rows_bias(uint32_t dig) { return dig > ROWS_BIAS ? dig - ROWS_BIAS : ROWS_NEVER; }
+__device__ __forceinline__ uint32_t rows_bias(uint32_t dig, uint32_t bias) { return dig > bias ? dig - bias : ROWS_NEVER; }
+// Two layouts of the 32-bit digest a stream position holds (offsim_streams.format):
+//   A  [T21 | done | z_next 10]                          threshold to 21 bits; the local row is the 16-bit loc entry (segments <= 65536 rows)
+//   B  [T16 | hi 6..2 | done | hi 1..0 | z_next 8]       threshold to 16 bits; hi = bits 16..22 of the local row, the loc entry its low 16
+//                                                        bits (segments of up to 2^23 rows, <= 256 states): still 4 + 2 bytes per position
+// Everything that differs between them is a constant of the launch: where the threshold starts, which low bits travel with a key, the
+// bias and the exact-look band (in threshold units: 16 and 17 of T21, 2 and 3 of T16), how a draw is laid down in the ring.
+struct RowsFormat {
+    uint32_t tshift, paymask, zmask, smask, bias, amb, emask;
+};
+__host__ __device__ constexpr RowsFormat rows_format(int fmt) {  // (the format is a template parameter of the kernel: these are immediates)
+    return fmt == OFFSIM_STREAMS_B ? RowsFormat{16u, 0xffffu, 0x4ffu, 0xffu, 2u << 16, 0u - (3u << 16), ROWS_LOG_KMASK | 0xfb00u}
+                                   : RowsFormat{11u, 0x7ffu, 0x7ffu, 0x3ffu, ROWS_BIAS, ROWS_AMB, ROWS_LOG_KMASK};
+}
+// bits 16.. of the local row out of a format-B payload (digest or key): bits 8, 9 and 11..15
+__device__ __forceinline__ uint32_t rows_loc_hi(uint32_t pay) { return ((pay >> 8) & 3u) | (((pay >> 11) & 0x1fu) << 2); }
 
 __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst_uniform) {
     uint32_t keep;
@@ -168,7 +192,7 @@ __device__ __noinline__ uint64_t rows_exact53(const uint64_t *__restrict__ rng4,
 //   beyond the SY_GEN it has read, the helper never generates beyond SY_C + 240 of the 256 ring entries.  This relies on the
 //   LDS executing the DS instructions of ONE wavefront in issue order (data before flag); every wait is bounded
 //   (ROWS_SPIN_LIMIT) and ends the rollout with OFFSIM_ST_PROTOCOL instead of hanging the stream.
-template <bool TRACE, bool HELPER>
+template <bool TRACE, bool HELPER, int FMT>
 __global__ void __launch_bounds__(HELPER ? 512 : 256)
     k_eval_mc_rows(offsim_table t, offsim_rollouts ro, offsim_streams sm, const uint64_t *__restrict__ keys, double gamma,
                    const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out,
@@ -192,11 +216,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const int64_t r = (int64_t)blockIdx.x * rpb + rid;
     const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this pair's DMA slots
     const uint32_t rbase = seg_a + seg_bytes + n_chain * ROWS_DMA_BYTES + rid * region_bytes;
-    auto dma_slot = [&](uint32_t slot) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
+    auto dma_slot = [&](uint32_t slot) __attribute__((always_inline)) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
 #define ROWS_READ_A() LV128(dma_a + DS_RQA * 256u + lane * 16u)
 
     const uint32_t win_a = rbase + RO_WIN, cons_a = win_a + n_slots * 32u, land_a = cons_a + n_slots * 4u, claim_a = land_a + n_slots * 4u;
     const uint32_t sync_a = rbase + RO_SYNC;
+    constexpr RowsFormat F = rows_format(FMT);
+    constexpr bool fmt_b = FMT == OFFSIM_STREAMS_B;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
     if (HELPER && !is_helper && li < 8u) LV32(sync_a + li4) = 0u;
@@ -209,7 +235,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t lifield = ((li & 7u) + 1u) << ROWS_LIF;
 
     __syncthreads();
-    auto seg_at = [&](uint32_t s) -> uint32_t { return LV32(seg_a + s * 4u); };
+    auto seg_at = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t { return LV32(seg_a + s * 4u); };
 
     const uint32_t *dbase = sm.dig + rr * sm.dig_stride;
     const uint16_t *lbase = sm.loc ? sm.loc + rr * sm.loc_stride : nullptr;
@@ -227,7 +253,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t c0 = cur_glb[s], beg = seg_at(s), len = seg_at(s + 1u) - beg;
         const uint32_t left = len - c0, want = left < ROWS_W ? left : ROWS_W;
 #pragma unroll
-        for (uint32_t e = 0; e < ROWS_W; e++) LV32(win_a + s * 32u + e * 4u) = e < want ? rows_bias(dbase[beg + c0 + e]) : ROWS_EMPTY;
+        for (uint32_t e = 0; e < ROWS_W; e++) LV32(win_a + s * 32u + e * 4u) = e < want ? rows_bias(dbase[beg + c0 + e], F.bias) : ROWS_EMPTY;
         LV32(cons_a + s * 4u) = c0;
         LV32(land_a + s * 4u) = c0 + want;
         LV8(claim_a + s) = 0u;
@@ -244,8 +270,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     }
     const U128 mult16 = u128(0xb6a4239f3b315f84ull, 0xf6ef6d3d288c03c1ull);  // PCG multiplier ** 16 mod 2**128
     uint32_t gen = 0, c = 0;  // draws generated (HELPER chain: known to be generated) / consumed since kernel start
-    auto gen16 = [&]() {
-        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = ((uint32_t)(pcg_output(lane_state) >> 43) << 11) | 0x7ffu;
+    auto gen16 = [&]() __attribute__((always_inline)) {
+        const uint32_t top = (uint32_t)(pcg_output(lane_state) >> 32);  // (the draw's top bits down to the threshold's resolution, ones below)
+        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = top | ((1u << F.tshift) - 1u);
         lane_state = add128(mul128(mult16, lane_state), plus16);
         gen += 16u;
     };
@@ -254,7 +281,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         for (int i = 0; i < 15; i++) gen16();  // 240 draws ahead
     }
     // bounded wait of the hand-off protocol: polls `ready` until it holds; false if it gave up
-    auto spin_until = [&](auto ready) -> bool {
+    auto spin_until = [&](auto ready) __attribute__((always_inline)) -> bool {
         for (uint32_t n = 0; n < ROWS_SPIN_LIMIT; n++) {
             if (ready()) return true;
             __builtin_amdgcn_s_sleep(4);
@@ -264,7 +291,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // HELPER chain: at least m draws beyond c are in the ring (published by the helper), or the rollout stops
     int status = OFFSIM_ST_OK;
     uint32_t nlog_dead = 0;  // steps the row logged in the tick it stopped in
-    auto need_draws = [&](uint32_t m, uint32_t logged) {
+    auto need_draws = [&](uint32_t m, uint32_t logged) __attribute__((always_inline)) {
         if (HELPER) {
             if (gen - c >= m) return;
             LV32(sync_a + SY_C) = c;  // the helper generates up to 240 beyond what it knows to be consumed
@@ -290,12 +317,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t ic0 = ro.init_cursor[rr], init_a = rbase + RO_INIT;
     uint32_t ic = ic0, filled = ic0, ep = 0, pf_st = 0;
     int pf_v = -1;
-    auto prefetch_rows = [&]() {
+    auto prefetch_rows = [&]() __attribute__((always_inline)) {
         const uint32_t k = filled + li;
         pf_v = k < N0 ? (init_row ? (int)init_row[k] : (int)k) : -1;
         pf_st = 1u;
     };
-    auto prefetch_step = [&]() {
+    auto prefetch_step = [&]() __attribute__((always_inline)) {
         if (pf_st == 2u) {
             if ((int32_t)(filled - ic) <= 16) {  // the half these 16 go to has been consumed
                 LV32(init_a + (((filled + li - ic0) & 31u) << 2)) = (uint32_t)pf_v;
@@ -315,11 +342,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 
     // ---- per-row state ----
     uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
+    uint32_t logh_a = rbase + RO_LOGH;  // ... and its side bytes (format B: local-row high bits of the steps logged in the long form)
     uint32_t z = 0;  // current state slot
     uint32_t n_dry = 0, n_tie = 0, n_tick = 0, n_late = 0, n_miss = 0, n_req = 0;
     // refill: one outstanding request per lane
     uint32_t rq_s = 0, rq_p = 0, rq_n = 0;
     // reward pipeline, three ticks deep (R1: row index + discount, R2: reward, R3: in-order sums)
+    uint32_t lh1 = 0;
     uint32_t rowb1 = 0, half1 = 0, pop1 = 0, n1 = 0, n2 = 0, dm1 = 0, dm2 = 0, st1 = 0;
     uint64_t any1 = 0, any2 = 0;
     double gp2 = 0.0, gpx1 = 0.0;
@@ -328,7 +357,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     double G = 0.0, sum_g = 0.0;
 
     // env.reset() (psrs.py:32-37, :249-252): the next initial state, or the rollout stops
-    auto do_reset = [&](uint32_t logged) {
+    auto do_reset = [&](uint32_t logged) __attribute__((always_inline)) {
         if (ep >= max_episodes) {  // psrs.py:248
             dead = 1u;
             nlog_dead = logged;
@@ -349,38 +378,39 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 
     // chain registers: w = this lane's window entry of the current state (read from ra), kt = its draw
     uint32_t ra = 0, w = 0, kt = 0;
-    auto issue_reads = [&]() {
+    auto issue_reads = [&]() __attribute__((always_inline)) {
         const uint32_t zz = dead ? 0u : z;
         ra = win_a + zz * 32u + li4w;
         w = LV32(ra);
         kt = LV32(ring_a + (((c << 2) + li4w) & (ROWS_RING * 4u - 4u)));
     };
     // entries the window of the row's current state holds (head-aligned: they come first), from the look's entries
-    auto held = [&](uint32_t wv) -> uint32_t {
+    auto held = [&](uint32_t wv) __attribute__((always_inline)) -> uint32_t {
         const uint64_t b = __ballot(wv != ROWS_EMPTY);
         return (uint32_t)__popc((uint32_t)(b >> (rw * 16u)) & 0xffu);
     };
     // the look of the hand-scheduled loop, restated for the iterations that run outside it (some row of the wavefront has
     // stopped, or TRACE): key as there, amb = some lane of the row needs the exact look
-    auto look = [&](uint32_t &key, bool &amb) {
+    auto look = [&](uint32_t &key, bool &amb) __attribute__((always_inline)) {
         const uint32_t d = w - kt;
-        key = row_min16(kt > w ? 0xffffffffu : ((w & 0x7ffu) | lifield));
-        amb = row_min16(d >= ROWS_AMB ? 0u : 1u) == 0u;
+        key = row_min16(kt > w ? 0xffffffffu : ((w & F.paymask) | lifield));
+        amb = row_min16(d >= F.amb ? 0u : 1u) == 0u;
     };
 
     // the step's bookkeeping for a clear accept of window entry k1-1 with payload `key`
-    auto commit = [&](uint32_t key, uint32_t k1, uint32_t it) {
+    auto commit = [&](uint32_t key, uint32_t k1, uint32_t it) __attribute__((always_inline)) {
         c += k1;
         LV32(log_a + it * 4u) = rows_log_word(z, key & 0x400u, k1);
+        if (fmt_b) lds_w16(logh_a + it * 2u, rows_loc_hi(key));
         const uint32_t k1x4 = k1 << 2;
         LV32(((li4w - k1x4) & 28u) | (ra - li4w)) = li4w < k1x4 ? ROWS_EMPTY : w;  // (lanes 8..15 repeat the stores of lanes 0..7)
-        z = key & 0x3ffu;
+        z = key & F.smask;
     };
 
     // exact path: candidates of state z straight from the stream, starting at queue position cz (`popped` candidates of the
     // step are consumed already), until one is accepted (completes the step: log, window = the candidates behind it, land) or
     // the queue ends (the rollout stops)
-    auto direct = [&](uint32_t it, uint32_t cz, uint32_t popped) {
+    auto direct = [&](uint32_t it, uint32_t cz, uint32_t popped) __attribute__((always_inline)) {
         for (;;) {
             const uint32_t beg = seg_at(z), len = seg_at(z + 1u) - beg;
             if (len == 0u) {  // KeyError (psrs.py:44)
@@ -411,29 +441,30 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint32_t nv = rem < in_sector ? rem : in_sector;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
-            const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> 11;
-            bool ok = valid && k21 <= (dg >> 11);
-            if (ok && k21 == (dg >> 11)) {  // top-21-bit tie: k53 of draw c+li against the full T
-                const uint32_t lc = lbase ? (uint32_t)lbase[beg + cz + li] : cz + li;
+            const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> F.tshift;
+            bool ok = valid && k21 <= (dg >> F.tshift);
+            if (ok && k21 == (dg >> F.tshift)) {  // tie at the digest's resolution: k53 of draw c+li against the full T
+                const uint32_t lc = lbase ? ((uint32_t)lbase[beg + cz + li] | (fmt_b ? rows_loc_hi(dg) << 16 : 0u)) : cz + li;
                 ok = !(rows_exact53(rng4, (uint64_t)c + li + 1u) > key_T(keys[beg + lc]));
             }
-            const uint32_t fk = row_min16(ok ? ((li << 11) | (dg & 0x7ffu)) : 0xffffffffu);  // first accepted lane and its done / z_next
+            const uint32_t fk = row_min16(ok ? ((li << 16) | (dg & 0xffffu)) : 0xffffffffu);  // first accepted lane and the low half of its digest
             if (fk == 0xffffffffu) {  // all of them rejected: consumed (one draw each)
                 c += nv;
                 cz += nv;
                 popped += nv;
                 continue;
             }
-            const uint32_t acc = fk & 0x7ffu;
-            const uint32_t k1 = (fk >> 11) + 1u;
+            const uint32_t acc = fk & 0xffffu;
+            const uint32_t k1 = (fk >> 16) + 1u;
             c += k1;
             const uint32_t cz1 = cz + k1;
             LV32(log_a + it * 4u) = rows_log_word(z, acc & 0x400u, popped + k1);
+            if (fmt_b) lds_w16(logh_a + it * 2u, rows_loc_hi(acc));
             const uint32_t keep = nv - k1 < ROWS_W ? nv - k1 : ROWS_W;  // the candidates behind it become the window
             if (li < 8u) LV32(win_a + z * 32u + li4) = ROWS_EMPTY;
-            if (li >= k1 && li < k1 + keep) LV32(win_a + z * 32u + ((li - k1) << 2)) = rows_bias(dg);
+            if (li >= k1 && li < k1 + keep) LV32(win_a + z * 32u + ((li - k1) << 2)) = rows_bias(dg, F.bias);
             LV32(land_a + z * 4u) = cz1 + keep;
-            z = acc & 0x3ffu;
+            z = acc & F.smask;
             if (acc & 0x400u) {
                 ep++;
                 do_reset(it + 1u);
@@ -445,7 +476,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // the look did not give the row a clear accept.  A lane near a tie: the exact look starts at the head of the queue, which is
     // land - (entries held); what the window rejected is rejected again, with the same draws.  No lane near a tie: every
     // candidate the window holds is a clear reject (or it holds none), they are consumed and the exact look starts behind them.
-    auto exact_step = [&](uint32_t it, bool amb) {
+    auto exact_step = [&](uint32_t it, bool amb) __attribute__((always_inline)) {
         const uint32_t hv = held(w), ld = LV32(land_a + z * 4u);
         if (amb) {
             n_tie++;
@@ -458,7 +489,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     };
 
     // one iteration of a live row outside the hand-scheduled loop
-    auto slow_step = [&](uint32_t key, bool amb, uint32_t it) {
+    auto slow_step = [&](uint32_t key, bool amb, uint32_t it) __attribute__((always_inline)) {
         if (key != 0xffffffffu && !amb) {  // clear accept: the row's event, if any, is the episode end or low draws
             commit(key, (key >> ROWS_LIF) & 15u, it);
             if (key & 0x400u) {
@@ -486,7 +517,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // in-order discounted sums (bit-exact Gs).  Runs in the chain wavefront's tick, or in the helper wavefront (HELPER).
     uint32_t in_loc = 0, in_gplo = 0, in_gphi = 0;
     // first half: what the previous tick's loads brought, and R3 (no new load is issued here)
-    auto rewards_a = [&]() {
+    auto rewards_a = [&]() __attribute__((always_inline)) {
         in_loc = dma_slot(DS_LOC);
         {
             const scan_u32x4 gpq = LV128(dma_a + DS_GP * 256u + lane * 16u);
@@ -543,10 +574,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // atomic does all of it: the LDS applies the lanes of a ds_add_rtn_u32 that hit one address in ascending lane order (= step
     // order), so a lane gets back exactly the cursor as its step found it (tools/micro/lds_atomic_order.hip checks this on the
     // hardware; offsim_selftest_lds_atomic_order is the same check behind the C ABI).
-    auto positions = [&](uint32_t n, uint32_t e) -> uint32_t {
+    auto positions = [&](uint32_t n, uint32_t e) __attribute__((always_inline)) -> uint32_t {
         uint32_t pos = 0;
         if (li < n) {
-            const uint32_t ca = cons_a + (e & 0x3ffu) * 4u, k_i = rows_log_k(e);
+            const uint32_t ca = cons_a + (e & F.smask) * 4u, k_i = rows_log_k(e);
             uint32_t pre;
             asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pre) : "v"(ca), "v"(k_i) : "memory");
             pos = pre + k_i - 1u;
@@ -554,16 +585,16 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         return pos;
     };
     // second half: R2 and R1 issue this tick's loads
-    auto rewards_b = [&](uint32_t n, uint32_t e_i, uint32_t pos_i) {
+    auto rewards_b = [&](uint32_t n, uint32_t e_i, uint32_t pos_i, uint32_t lochi_i) __attribute__((always_inline)) {
         const bool mine = li < n;
-        const uint32_t s_i = e_i & 0x3ffu, pop_i = rows_log_k(e_i);
+        const uint32_t s_i = e_i & F.smask, pop_i = rows_log_k(e_i);
         const bool done_i = mine && (e_i & 0x400u);
         // R2: rewards of the steps of one tick ago (row = segment start + local row, the latter from the loc stream)
         {
             // (Every load of the pipeline is issued by every lane -- one without work reads the rollout's own stream state -- so
             // that a round issues a FIXED number of vector-memory instructions: the helper's waits count them, ROWS_VM_*.)
             const bool act = li < n1;
-            const uint32_t lc = lbase ? ((half1 ? in_loc >> 16 : in_loc) & 0xffffu) : in_loc;
+            const uint32_t lc = lbase ? (((half1 ? in_loc >> 16 : in_loc) & 0xffffu) | (lh1 << 16)) : in_loc;
             const uint32_t g = rowb1 + lc;
             if (r64) {
                 const uint32_t *src = act ? (const uint32_t *)((const double *)t.r + g) : (const uint32_t *)rng4;
@@ -603,6 +634,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             bx1 = mine && !in_table;  // the table's last entry or beyond it (csrc/discount.hpp): worked out here, used in place of the slot
             if (bx1) gpx1 = discount_at(gamma_pow, n_gamma_pow, gamma, (uint64_t)t_i);
             rowb1 = rb;
+            lh1 = fmt_b ? lochi_i : 0u;
             half1 = hf;
             pop1 = pop_i;
             dm1 = dmrow;
@@ -620,7 +652,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // step was logged), as one or two 16-byte LDS-DMA loads into this pair's request areas.  Returns what it asked for
     // (0 = nothing).  (The loads fetch whole groups of four; a request that would read beyond the table's last row is left to
     // the exact path.)
-    auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) {
+    auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) __attribute__((always_inline)) {
         q_n = 0;
         const uint32_t sa = mine ? s_i : 0u;  // (a lane without a step looks at state 0 and asks for nothing)
         if (mine) LV8(claim_a + s_i) = (uint8_t)li;
@@ -708,6 +740,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint32_t la = rbase + ((k & 1u) ? RO_LOG2 : RO_LOG);
             const uint32_t n = LV32(sync_a + ((k & 1u) ? SY_N1 : SY_N0));
             const uint32_t le = LV32(la + li4);
+            // (format B: bits 16.. of the served candidate's local row -- in the log word itself, or beside it for a step logged in the long form)
+            const uint32_t le_hi = !fmt_b ? 0u : (le >> 31) ? lds_r16(rbase + RO_LOGH + ((k & 1u) ? 32u : 0u) + li * 2u) : rows_loc_hi(le);
             fin = LV32(sync_a + SY_FIN);
             cp = LV32(sync_a + SY_C);
             LV32(sync_a + SY_HTICK) = k + 1u;  // (behind the reads of the buffer: the chain may reuse it)
@@ -717,8 +751,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             {   // the window top-ups this tick's steps call for, first of all (the chain lands them at the end of its next tick:
                 // what has not arrived by then is lost)
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
-                request(li < n, le & 0x3ffu, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
-                LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_s << 17) | (q_n << 27)) : 0u;
+                request(li < n, le & F.smask, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
+                LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_n << 28)) : 0u;
+                LV32(dma_a + DS_RQS * 256u + lane * 4u) = q_s;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
 #ifdef ROWS_DIAG_LAG
@@ -736,7 +771,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (ROWS_RQ_MAX > 4u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             rewards_a();
-            rewards_b(n, le, pos_i);
+            rewards_b(n, le, pos_i, le_hi);
             if (gen - cp < 240u) {
                 while (gen - cp < 240u) gen16();
                 LV32(sync_a + SY_GEN) = gen;
@@ -747,7 +782,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         for (int dr = 0; dr < 2; dr++) {  // drain the pipeline (R2, R3 of the last ticks)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             rewards_a();
-            rewards_b(0u, 0u, 0u);
+            rewards_b(0u, 0u, 0u, 0u);
         }
         if (fin == (uint32_t)OFFSIM_ST_EXHAUSTED + 1u) {  // psrs.py:265: the cut-short episode still logs its length
             if (li == 0u && r < (int64_t)ro.R && out.ep_len && (int64_t)n_len <= out.ep_cap) out.ep_len[r * (out.ep_cap + 1) + n_len] = (int32_t)len_acc;
@@ -780,7 +815,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 
     // ---- the chain wavefront's tick, once per 16 iterations; lane = step of the tick ----
     uint32_t tick_k = 0;
-    auto tick = [&]() {
+    auto tick = [&]() __attribute__((always_inline)) {
 #ifdef OFFSIM_ROWS_PROF
         pf_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -813,7 +848,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             // this tick ran), the descriptors and digests of that round.  A flag that is not there yet is rare (the helper is a
             // tick ahead); only then are the reads repeated behind a bounded wait.
             const uint32_t v_req = LV32(sync_a + SY_REQ);
-            uint32_t dsc = dma_slot(DS_RQD);
+            uint32_t dsc = dma_slot(DS_RQD), dss = dma_slot(DS_RQS);
             in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
             if (tick_k >= 1u) {
                 const uint32_t want_r = tick_k;
@@ -822,12 +857,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                         status = OFFSIM_ST_PROTOCOL;
                         dead = 1u;
                     }
-                    dsc = dma_slot(DS_RQD);
+                    dsc = dma_slot(DS_RQD), dss = dma_slot(DS_RQS);
                     in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
                 }
-                rq_p = dsc & 0x1ffffu;
-                rq_s = (dsc >> 17) & 0x3ffu;
-                rq_n = dsc >> 27;  // (<= 8)
+                rq_p = dsc & 0xfffffffu;
+                rq_s = dss;
+                rq_n = dsc >> 28;  // (<= 8)
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
@@ -863,15 +898,15 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             k = k < room ? k : room;
             const uint32_t dst = win_a + rq_s * 32u + (land_have << 2);
             const uint32_t scratch = sync_a + 64u + li4;  // (the hand-off words end at 32)
-            LV32(k > 0u ? dst : scratch) = rows_bias(in_a.x);
-            LV32(k > 1u ? dst + 4u : scratch) = rows_bias(in_a.y);
-            LV32(k > 2u ? dst + 8u : scratch) = rows_bias(in_a.z);
-            LV32(k > 3u ? dst + 12u : scratch) = rows_bias(in_a.w);
+            LV32(k > 0u ? dst : scratch) = rows_bias(in_a.x, F.bias);
+            LV32(k > 1u ? dst + 4u : scratch) = rows_bias(in_a.y, F.bias);
+            LV32(k > 2u ? dst + 8u : scratch) = rows_bias(in_a.z, F.bias);
+            LV32(k > 3u ? dst + 12u : scratch) = rows_bias(in_a.w, F.bias);
             if (ROWS_RQ_MAX > 4u && __ballot(k > 4u) != 0ull) {
-                LV32(k > 4u ? dst + 16u : scratch) = rows_bias(in_b.x);
-                LV32(k > 5u ? dst + 20u : scratch) = rows_bias(in_b.y);
-                LV32(k > 6u ? dst + 24u : scratch) = rows_bias(in_b.z);
-                LV32(k > 7u ? dst + 28u : scratch) = rows_bias(in_b.w);
+                LV32(k > 4u ? dst + 16u : scratch) = rows_bias(in_b.x, F.bias);
+                LV32(k > 5u ? dst + 20u : scratch) = rows_bias(in_b.y, F.bias);
+                LV32(k > 6u ? dst + 24u : scratch) = rows_bias(in_b.z, F.bias);
+                LV32(k > 7u ? dst + 28u : scratch) = rows_bias(in_b.w, F.bias);
             }
             if (k) LV32(land_a + rq_s * 4u) = land_ld + k;
             rq_n = 0;
@@ -893,11 +928,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             steps += n;
             tick_k++;
             log_a = rbase + ((tick_k & 1u) ? RO_LOG2 : RO_LOG);
+            logh_a = rbase + RO_LOGH + ((tick_k & 1u) ? 32u : 0u);
         } else {
             const uint32_t pos_i = positions(n, le);
-            request(li < n, le & 0x3ffu, rq_s, rq_p, rq_n);
+            request(li < n, le & F.smask, rq_s, rq_p, rq_n);
             rewards_a();
-            rewards_b(n, le, pos_i);
+            rewards_b(n, le, pos_i, !fmt_b ? 0u : (le >> 31) ? lds_r16(logh_a + li * 2u) : rows_loc_hi(le));
             if (!dead) {
                 prefetch_step();
                 while (gen - c < 240u) gen16();
@@ -917,7 +953,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // stores of the step as the loop had prepared them (valid for the rows whose look was a clear accept)
     uint32_t ex_key = 0, ex_d = 0, ex_slot = 0;
     uint64_t ex_amb = 0;
-    auto fast_run = [&](uint32_t &it, uint64_t live) {
+    auto fast_run = [&](uint32_t &it, uint64_t live) __attribute__((always_inline)) {
         // episode ends the loop may serve itself: after this many the episode cap, the end of the init queue or the end of
         // what is stored in the ring is reached and the C++ path has to look
         const uint32_t initp0 = init_a + (((ic - ic0) & 31u) << 2);
@@ -947,7 +983,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             BACK ":\n\t"                                                                                                  \
             "s_waitcnt lgkmcnt(0)\n\t"                                   /* this look's entry and draw */                \
             "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */                \
-            "v_and_or_b32 %[key], " W ", %[s7ff], %[lif]\n\t"            /* (lane + 1) << 26 | done << 10 | z_next */    \
+            "v_and_or_b32 %[key], " W ", %[spay], %[lif]\n\t"            /* (lane + 1) << 26 | the digest's low bits: done << 10 | z_next (| local-row high bits) */ \
             "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
             "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"              /* (two instructions behind the one that wrote vcc, two ahead of the DPP read) */ \
             "s_nop 1\n\t"                                                                                                 \
@@ -956,7 +992,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
             "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
-            "v_and_b32 " ZN ", %[s7ff], %[key]\n\t"                      /* next state (| done << 10: an event) */      \
+            "v_and_b32 " ZN ", %[szm], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
             "v_add_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
             "v_cmp_lt_u32_e64 %[ev], %[srmask], " ZN "\n\t"              /* episode end, or the all-ones key of a row without a clear accept (states are < 0x3fc) */ \
             "v_sub_co_u32_sdwa %[tt], vcc, %[li4w], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
@@ -980,7 +1016,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             EPI ":\n\t"                                                                                                    \
             "s_cmp_lg_u64 %[amb], 0\n\t"                                                                                   \
             "s_cbranch_scc1 " OUT "f\n\t"                               /* a lane needs the exact look */                  \
-            "v_cmp_le_u32_e32 vcc, 0x500, " ZN "\n\t"                   /* all-ones key: a row without a clear accept */   \
+            "v_cmp_eq_u32_e32 vcc, -1, %[key]\n\t"                     /* all-ones key: a row without a clear accept */   \
             "s_cbranch_vccnz " OUT "f\n\t"                                                                                 \
             "v_cmp_le_u32_e32 vcc, 0x400, " ZN "\n\t"                   /* vcc: the rows whose episode ends */             \
             "v_cmp_eq_u32_e64 %[ev], 0, %[left]\n\t"                                                                       \
@@ -1077,7 +1113,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
               [key] "=&v"(key), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd), [e] "=&v"(e), [zn] "=&v"(zn), [rb] "=&v"(rb), [w2] "=&v"(w2),
               [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
             : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [li4w] "v"(li4w), [logb] "v"(log_a),
-              [s7ff] "s"(0x7ffu), [samb] "s"(ROWS_AMB), [srmask] "s"(ROWS_RING * 4u - 4u), [skm] "s"(ROWS_LOG_KMASK), [live] "s"(live)
+              [spay] "s"(F.paymask), [szm] "s"(F.zmask), [samb] "s"(F.amb), [srmask] "s"(ROWS_RING * 4u - 4u), [skm] "s"(F.emask), [live] "s"(live)
             : "vcc", "scc", "memory", "s20", "s21", "s22", "s24", "s25");
 #undef ROWS_STEP
 #undef ROWS_EPI
@@ -1100,14 +1136,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         ex_amb = amb;
     };
     // the iteration the loop was left in, from what it handed over (no second look, no re-read of the window)
-    auto resume_step = [&](uint32_t it) {
+    auto resume_step = [&](uint32_t it) __attribute__((always_inline)) {
         const uint32_t key = ex_key;
         const bool amb = ((uint32_t)(ex_amb >> (rw * 16u)) & 0xffffu) != 0u;
         if (key != 0xffffffffu && !amb) {  // clear accept: the stores the loop had prepared, then the episode end if that was the event
-            LV32(log_a + it * 4u) = (key & ROWS_LOG_KMASK) | z | (key & 0x400u);
+            LV32(log_a + it * 4u) = (key & (F.emask | 0x400u)) | z;
             LV32(ex_slot) = ex_d;
             c += (key >> ROWS_LIF) & 15u;
-            z = key & 0x3ffu;
+            z = key & F.smask;
             if (key & 0x400u) {
                 ep++;
                 do_reset(it + 1u);

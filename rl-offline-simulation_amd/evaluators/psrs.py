@@ -101,9 +101,10 @@ class BatchedPSRS:
                     self._dig_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
                     self._loc_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int16, device=dev)
                 keys, dig32 = self._policy_keys(policy)
-                L.check(L.load().offsim_shuffle_queues_keys(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), L.ptr(self._dig_buf),
+                L.check(L.load().offsim_shuffle_queues_keys(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), self._stream_format(), L.ptr(self._dig_buf),
                                                             L.ptr(self._loc_buf), L.ptr(self._init_perm_buf), L.stream_ptr()))
-                self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=self._policy_key(policy))
+                self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=self._policy_key(policy),
+                                     format=self._stream_format())
                 self.state.set_orders(None, 0, self._init_perm_buf, t.N0)
                 self._perm_lazy = "streams"
             else:
@@ -120,13 +121,13 @@ class BatchedPSRS:
             if keyed:  # one shared order: the streams are one row, built from the permutation
                 keys, dig32 = self._policy_keys(policy)
                 p = perm[0, :t.N].to(torch.int64) & 0xFFFFFFFF
-                self._streams = dict(dig=dig32[p].contiguous(), dig_stride=0, loc=(p - self._seg_base()).to(torch.int16).contiguous(),
-                                     loc_stride=0, key=self._policy_key(policy))
+                dg, lc = self._pack_streams(dig32, p)
+                self._streams = dict(dig=dg, dig_stride=0, loc=lc, loc_stride=0, key=self._policy_key(policy), format=self._stream_format())
         elif shuffle == SHUFFLE_NONE:
             self.state.set_orders(None, 0, None, 0)
             if keyed:
                 keys, dig32 = self._policy_keys(policy)
-                self._streams = dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=self._policy_key(policy))
+                self._streams = self._table_order_streams(dig32, self._policy_key(policy))
         else:
             raise ValueError(shuffle)
 
@@ -137,8 +138,13 @@ class BatchedPSRS:
         t = self.table
         p = policy if isinstance(policy, torch.Tensor) else np.asarray(policy)
         f64 = p.dtype in (torch.float64, np.float64, np.dtype(np.float64))
-        return (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= 65536 and t.N < 2 ** 32 - 1
+        return (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
                 and os.environ.get("OFFSIM_SCAN_ROWS", "1") != "0")
+
+    def _stream_format(self):
+        """Layout of the digest stream (include/offsim.h): A while every state has at most 65536 rows (21-bit thresholds, 16-bit local
+        rows), B beyond (16-bit thresholds, the local row's upper bits inside the digest)."""
+        return L.STREAMS_A if self.table.max_seg <= 65536 else L.STREAMS_B
 
     @staticmethod
     def _policy_key(policy):
@@ -157,7 +163,7 @@ class BatchedPSRS:
             keys = self.compile_policy(pi_d)
             if getattr(self, "_dig32", None) is None:
                 self._dig32 = torch.empty(max(t.N, 1), dtype=torch.int32, device=t.device)
-            L.check(L.load().offsim_compile_digests(C.byref(t.c), L.ptr(keys), L.ptr(self._dig32), L.stream_ptr()))
+            L.check(L.load().offsim_compile_digests(C.byref(t.c), L.ptr(keys), self._stream_format(), L.ptr(self._dig32), L.stream_ptr()))
             self._pk_cache = (k, keys, self._dig32)
         return self._pk_cache[1], self._pk_cache[2]
 
@@ -173,11 +179,30 @@ class BatchedPSRS:
         key = self._policy_key(policy) if key is None else key
         keys, dig32 = self._policy_keys(policy, key=key)
         if st.perm is None:  # table order
-            self._streams = dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=key)
+            self._streams = self._table_order_streams(dig32, key)
             return
         p = st.perm.reshape(n_rows, -1)[:, :t.N].to(torch.int64) & 0xFFFFFFFF
-        self._streams = dict(dig=dig32[p].contiguous(), dig_stride=t.N if n_rows > 1 else 0,
-                             loc=(p - self._seg_base()[None, :]).to(torch.int16).contiguous(), loc_stride=t.N if n_rows > 1 else 0, key=key)
+        dg, lc = self._pack_streams(dig32, p)
+        self._streams = dict(dig=dg, dig_stride=t.N if n_rows > 1 else 0, loc=lc, loc_stride=t.N if n_rows > 1 else 0, key=key,
+                             format=self._stream_format())
+
+    def _pack_streams(self, dig32, p):
+        """(dig, loc) streams of queue orders given as grouped rows p [..., N] (int64): the digest of the row at every position -- in
+        format B with bits 16.. of its local row in the digest's bits 8, 9, 11..15 -- and the local row's low 16 bits."""
+        local = p - (self._seg_base() if p.dim() == 1 else self._seg_base()[None, :])
+        dg = dig32[p].to(torch.int64) & 0xFFFFFFFF
+        if self._stream_format() == L.STREAMS_B:
+            h = local >> 16
+            dg = dg | ((h & 3) << 8) | ((h >> 2) << 11)
+        dg = torch.where(dg >= 2 ** 31, dg - 2 ** 32, dg).to(torch.int32)
+        return dg.contiguous(), (local & 0xFFFF).to(torch.int16).contiguous()
+
+    def _table_order_streams(self, dig32, key):
+        """Streams of queues in table order (no shuffle): format A needs no loc stream (the local row is the queue position)."""
+        if self._stream_format() == L.STREAMS_A:
+            return dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=key, format=L.STREAMS_A)
+        dg, lc = self._pack_streams(dig32, torch.arange(self.table.N, device=self.table.device, dtype=torch.int64))
+        return dict(dig=dg, dig_stride=0, loc=lc, loc_stride=0, key=key, format=L.STREAMS_B)
 
     def _seg_base(self):
         """seg_off of the state every grouped position belongs to ([N] int64)."""
@@ -190,7 +215,11 @@ class BatchedPSRS:
         """Queue orders as permutations of grouped rows [R or 1, N] (built from the streams when the reset wrote those)."""
         if self.state.perm is not None or self._perm_lazy != "streams":
             return self.state.perm
-        return ((self._loc_buf.to(torch.int64) & 0xFFFF) + self._seg_base()[None, :]).to(torch.int32)
+        local = self._loc_buf.to(torch.int64) & 0xFFFF
+        if self._stream_format() == L.STREAMS_B:
+            dg = self._dig_buf.to(torch.int64)
+            local = local | ((((dg >> 8) & 3) | (((dg >> 11) & 0x1F) << 2)) << 16)
+        return (local + self._seg_base()[None, :]).to(torch.int32)
 
     def set_rejection_seeds(self, seeds, provider="pcg64"):
         """Replace only the rejection streams (env.rejection_sampling_rng = ..., psrs.py:20 is a plain attribute).
@@ -311,7 +340,8 @@ class BatchedPSRS:
         if rows:  # the sampler reset laid the orders out as candidate streams for this policy: row-packed scan
             keys, _ = self._policy_keys(pi_slots, key=pkey)
             sm = self._streams
-            smc = L.Streams(dig=L.ptr(sm["dig"]), dig_stride=sm["dig_stride"], loc=L.ptr(sm["loc"]), loc_stride=sm["loc_stride"])
+            smc = L.Streams(dig=L.ptr(sm["dig"]), dig_stride=sm["dig_stride"], loc=L.ptr(sm["loc"]), loc_stride=sm["loc_stride"],
+                            format=sm.get("format", L.STREAMS_A))
             L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
                                                     gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys, sm)
