@@ -252,9 +252,9 @@ def make_log(a, seed, dev):
     elif a.workload == "grid":
         from rl_offline_simulation_amd.encoders import HOMEREncoder
         e = synth.grid_coords_log_fast(N, seed=seed)
-        g = torch.Generator().manual_seed(0)  # nn.Linear's default init, fixed seed (no trained checkpoint travels)
-        lin = lambda o, i: ((torch.rand((o, i), generator=g) * 2 - 1) / i ** 0.5, (torch.rand(o, generator=g) * 2 - 1) / i ** 0.5)
-        (W1, b1), (W2, b2) = lin(64, 2), lin(25, 64)
+        # no trained checkpoint travels: weights that send an observation to its cell (synth.grid_cell_encoder_weights), so that all
+        # 25 abstract states are populated as under a trained HOMER encoder
+        W1, b1, W2, b2 = (torch.from_numpy(w) for w in synth.grid_cell_encoder_weights(5, 64, seed=0))
         enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
                                                       "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2}, device=dev)
         t_e = time.perf_counter()
@@ -420,7 +420,7 @@ def run(a):
                      "one RCCL all-reduce of per-seed (sum G, n episodes)" if strong else
                      f"weak: {world} logs of {a.transitions} transitions, one per GPU, all {R} seeds on each, one RCCL all-reduce of per-seed (sum G, n episodes)")
         wl = (f"CartPole-dynamics log, uniform logger, device box encoder (C2)" if a.workload == "cartpole" else
-              f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA with random-init weights (C3){enc_note}" if a.workload == "grid" else
+              f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA, weights built to map an observation to its cell (C3){enc_note}" if a.workload == "grid" else
               f"S-iid synthetic log (SURVEY 8d), nS={a.n_states}, nA={a.n_actions}")
         out = {
             "metric": "simulated steps/sec (node), 10M logged transitions x 4096 rollouts",

@@ -216,3 +216,22 @@ def grid_coords_log_fast(N, num_cells=5, num_steps=15, goal=(4, 4), seed=0, n_en
     return dict(observations=em(O), next_observations=em(NO), z=em(Z), z_next=em(ZN), actions=em(A),
                 rewards=em(Rw), terminals=em(D), steps=steps, episode_ids=np.cumsum(steps == 0) - 1,
                 action_distributions=np.full((N, 5), 0.2, np.float32))
+
+
+def grid_cell_encoder_weights(num_cells=5, hidden=64, seed=0, sharpness=200.0):
+    """Weights of a 2-`hidden`-num_cells^2 MLP (Linear, LeakyReLU, Linear) that sends a continuous_grid observation to its cell:
+    no trained HOMER checkpoint travels, and nn.Linear's default init leaves most of the 25 abstract states empty.  Hidden units 0
+    and 1 copy the (non-negative) coordinates; the readout scores cell k by sharpness * (2 c_k . x - |c_k|^2), the nearest cell centre
+    c_k = ((i + 0.5) / num_cells, (j + 0.5) / num_cells), k = i + num_cells * j (ContinuousGridEnv's state index,
+    continuous_grid.py:62-66); every other weight keeps nn.Linear's default init, so the product is still a dense 2-64-25 MLP whose
+    argmax differs from the true cell only within the noise of those units next to a cell boundary.  Returns (W1, b1, W2, b2), f32."""
+    g = np.random.default_rng(seed)
+    nz = num_cells * num_cells
+    lin = lambda o, i: (((g.random((o, i)) * 2 - 1) / i ** 0.5).astype(np.float32), ((g.random(o) * 2 - 1) / i ** 0.5).astype(np.float32))
+    (W1, b1), (W2, b2) = lin(hidden, 2), lin(nz, hidden)
+    W1[0], W1[1], b1[0], b1[1] = (1.0, 0.0), (0.0, 1.0), 0.0, 0.0
+    k = np.arange(nz)
+    c = np.stack([(k % num_cells + 0.5) / num_cells, (k // num_cells + 0.5) / num_cells], 1)
+    W2[:, 0:2] = (sharpness * 2.0 * c).astype(np.float32)
+    b2 += (-sharpness * (c * c).sum(1)).astype(np.float32)
+    return W1, b1, W2, b2

@@ -313,3 +313,15 @@ def test_restricted_loads_reads_pickled_gym_spaces_including_seeded_ones():
     assert isinstance(got[2], spaces.Box) and got[2].shape == (4,) and np.allclose(got[2].low, -1.5) and np.allclose(got[2].high, 2.0)
     with pytest.raises(pickle.UnpicklingError):
         restricted_loads(pickle.dumps(os.system))
+
+
+def test_grid_cell_encoder_weights_populate_all_25_states():
+    """bench.py's C3 encoder (no trained HOMER checkpoint travels): a dense 2-64-25 MLP whose argmax is the observation's cell
+    (continuous_grid.py:62-66) away from cell boundaries, so every abstract state has rows."""
+    from rl_offline_simulation_amd import synth
+    W1, b1, W2, b2 = synth.grid_cell_encoder_weights()
+    e = synth.grid_coords_log_fast(100_000, seed=3)
+    x = e["observations"].astype(np.float32)
+    h = x @ W1.T + b1
+    z = (np.maximum(h, np.float32(0.01) * h) @ W2.T + b2).argmax(1)
+    assert (z == e["z"]).mean() > 0.95 and np.bincount(z, minlength=25).min() > 0

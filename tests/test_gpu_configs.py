@@ -62,18 +62,27 @@ def test_c3_continuous_grid_learned_encoder(gpu):
     from rl_offline_simulation_amd import synth
     from rl_offline_simulation_amd.encoders import HOMEREncoder
     e = synth.grid_coords_log_fast(300_000, seed=3, n_envs=512)
-    g = np.random.default_rng(7)
-    W1, b1 = g.standard_normal((64, 2)).astype(np.float32), g.standard_normal(64).astype(np.float32)
-    W2, b2 = g.standard_normal((25, 64)).astype(np.float32) / 8, g.standard_normal(25).astype(np.float32) * 0.1
+    # no trained HOMER checkpoint travels: weights that send an observation to its cell, so that all 25 states have rows
+    W1, b1, W2, b2 = synth.grid_cell_encoder_weights(5, 64, seed=7)
     enc = HOMEREncoder(2, 5, 25, 64, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
                                                  "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2})
     z, zn = enc.encode(e["observations"]), enc.encode(e["next_observations"])
     zo, lo = O.mlp_encode(e["observations"], W1, b1, W2, b2)
     top2 = np.sort(lo, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-4
-    assert np.array_equal(z[clear], zo[clear]) and clear.mean() > 0.999
+    assert np.array_equal(z[clear], zo[clear]) and clear.mean() > 0.995
+    assert len(np.unique(z)) >= 20 and (z == e["z"]).mean() > 0.95
     pi = synth.dirichlet_policy(25, 5)
-    _check_against_oracle(e, z, zn, pi, 0.95, list(range(8)), gpu)
+    table, o = _check_against_oracle(e, z, zn, pi, 0.95, list(range(8)), gpu)
+    assert table.max_seg > 65536  # the start cell's rows: the second layout of the candidate streams
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    env = BatchedPSRS(table, 8)
+    env.reset_sampler(list(range(8)), policy=table.policy_slots(pi))  # the untraced path of the bench: keyed reset + row-packed scan
+    o2 = env.eval_mc(table.policy_slots(pi), 0.95)
+    torch.cuda.synchronize()
+    assert env.scan_variant() == "k_eval_mc_rows"
+    for k in ("steps", "cand", "n_ep", "sum_g"):
+        assert torch.equal(o2[k], o[k]), k
 
 
 def test_c5_fp16_buffer(gpu):
