@@ -1389,8 +1389,15 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     int waves = (int)((160u * 1024u - 1024u - seg_bytes) / (4u * region + ROWS_DMA_BYTES));
     waves = waves > 4 ? 4 : waves;
     if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
+#ifdef ROWS_EXPERIMENT_ISOLATE  // measurement build: two chain wavefronts + two helpers per CU (a workgroup that takes the CU's LDS alone), one wavefront per SIMD
+    waves = waves > 2 ? 2 : waves;
+#endif
     const int rpb = waves * 4;
+#ifdef ROWS_EXPERIMENT_ISOLATE
+    const size_t lds = 100 * 1024;
+#else
     const size_t lds = 1024 + seg_bytes + (size_t)waves * ROWS_DMA_BYTES + (size_t)rpb * region;
+#endif
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
