@@ -320,7 +320,8 @@ int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
  * offsim_compile_digests: dig32[g] = the digest of grouped row g in `format`, local-row bits zero (from offsim_compile_policy's keys).
  * offsim_shuffle_queues_keys: PSRS.reset_sampler's shuffles (psrs.py:22-23,29-30; same orders as offsim_shuffle_queues,
  *   bit for bit) written as those streams; init_perm_out as in offsim_shuffle_queues.  States of more than 65536 rows need
- *   format B (OFFSIM_EUNSUPPORTED otherwise): their chains are shuffled in place in dig_out and converted afterwards.
+ *   format B (OFFSIM_EUNSUPPORTED otherwise): their chains are shuffled in place in dig_out and converted afterwards (or see
+ *   offsim_shuffle_queues_keys_ws).
  * offsim_eval_mc_streams: evalMC_psrs (psrs.py:241-271) from the streams; same outputs, bit for bit, as offsim_eval_mc /
  *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide digest ties
  *   exactly.  Strides are in elements; stride 0 = one order shared by all rollouts; loc == NULL = queues in table order
@@ -338,6 +339,16 @@ typedef struct offsim_streams {
 int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, int32_t format, uint32_t *dig32_out, void *stream);
 int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
                                uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream);
+/* The same with a workspace lent by the caller (device memory, 8-byte aligned, contents irrelevant before and after): the states of
+ * more than 65536 rows are then shuffled chunk by chunk in LDS with sequential global traffic only (csrc/shuffle_chunk.hpp) instead
+ * of in place with a random line per swap.  offsim_shuffle_workspace_bytes(t, n) = the bytes n persistent workgroups use (one per
+ * compute unit is the most the call starts; 0 = the table has no such state); a smaller workspace runs fewer workgroups, one that
+ * holds none (or NULL) gives offsim_shuffle_queues_keys.  Orders are the same bit for bit.  A message list of the chunked kernel
+ * that overflowed (probability ~1e-15 per list) raises OFFSIM_FAULT_SHUFFLE (offsim_async_faults): the call's orders are void. */
+int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_workgroups);
+int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
+                                  uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
+                                  void *stream);
 int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro, const offsim_streams *sm, const uint64_t *keys,
                            double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,
                            const offsim_evalmc_out *out, void *stream);

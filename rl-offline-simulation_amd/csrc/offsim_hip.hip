@@ -22,6 +22,7 @@
 #include <rocrand/rocrand_kernel.h>  // device API of Philox4x32-10 (the OFFSIM_STREAM_PHILOX provider)
 
 #include "shuffle_wave.hpp"
+#include "shuffle_chunk.hpp"
 
 using namespace offsim;
 
@@ -264,7 +265,7 @@ static hipError_t allow_big_lds_fn(const void *fn, int bytes) {
 // wave-parallel exact Fisher-Yates (shuffle_wave.hpp), one workgroup per chain.  dig_out == NULL: orders as permutations of grouped
 // rows; otherwise the keyed form (digest stream + 16-bit local rows per queue position) for the state queues
 static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
-                          const uint32_t *dig32, uint32_t *dig_out, uint16_t *loc_out, hipStream_t st) {
+                          const uint32_t *dig32, uint32_t *dig_out, uint16_t *loc_out, hipStream_t st, bool big_segments_elsewhere = false) {
     const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
     const uint32_t min_seg = t->min_seg > 0 ? (uint32_t)(t->min_seg > 0xffffffffll ? 0xffffffffll : t->min_seg) : 1u;
     const uint32_t n0 = (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0);
@@ -272,8 +273,9 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG>), 160 * 1024));
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_SMALL>), 160 * 1024));
-    if (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16) {  // first: these chains are the long ones
-        hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
+    if ((max_seg > SHUF_CAP16 && !big_segments_elsewhere) || n0 > SHUF_CAP16) {  // first: these chains are the long ones
+        // (workgroups 0 .. n_perm-1 are the init queues: with the states' big segments served by the chunked kernel only those are launched)
+        hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)(big_segments_elsewhere ? n_perm : n_blocks)), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
                            t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
         LAUNCH_CHECK();
     }
@@ -352,8 +354,24 @@ __global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ s
     }
 }
 
-extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
-                                          uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream) {
+// Workspace of the chunked shuffle (shuffle_chunk.hpp): header (work counter, work list) + one message pool and one reply pool per
+// persistent workgroup, sized for the table's longest state.
+#define SHC_CB 32768u
+#define SHC_HEADER_BYTES 4096
+static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
+    const uint32_t n = (uint32_t)t->max_seg;
+    const uint64_t msg = shc_pool_entries(n, SHC_CB), rep = (uint64_t)((n + SHC_CB - 1u) / SHC_CB) * SHC_CB;
+    if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
+    return (int64_t)(msg + rep);
+}
+extern "C" int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_blocks) {
+    if (!t || n_blocks < 1 || t->max_seg <= (int64_t)SHUF_CAP16 || t->max_seg > (1ll << 23) || t->n_slots > 1000) return 0;
+    return SHC_HEADER_BYTES + (int64_t)n_blocks * shc_block_words(t, nullptr) * 8;
+}
+
+extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
+                                             uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
+                                             void *stream) {
     if (!t || !seeds || n_perm < 0 || !init_perm_out || (t->N > 0 && (!dig32 || !dig_out || !loc_out)))
         return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad argument%s");
     if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad format%s");
@@ -363,13 +381,41 @@ extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t 
         return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows: stream format B (or offsim_shuffle_queues)%s");
     if (big && (t->max_seg > (1ll << 23) || t->n_slots > 256)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 256 states%s");
     if (n_perm == 0) return OFFSIM_OK;
-    int rc = launch_shuffle(t, seeds, n_perm, big ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // the states that do not fit LDS: the chunked kernel when the caller lent a workspace that holds at least one workgroup's pools,
+    // otherwise in place in global memory (the state's slice of dig_out) and one more pass that turns the order into streams
+    uint32_t msg_cap = 0;
+    int64_t n_wg = 0, words = 0;
+    if (big && workspace && ((uintptr_t)workspace & 7u) == 0) {
+        words = shc_block_words(t, &msg_cap);
+        n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_wg = n_wg > cus ? cus : n_wg;  // one persistent workgroup per CU (its chunk takes the CU's LDS)
+    }
+    const bool chunked = n_wg >= 1;
+    int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
     if (rc || !big) return rc;
+    if (chunked) {
+        uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
+        hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, SHUF_CAP16, hdr + 64, hdr + 1, hdr);
+        LAUNCH_CHECK();
+        HIP_TRY(allow_big_lds((k_shuffle_chunked<SHC_CB>), 160 * 1024));
+        hipLaunchKernelGGL((k_shuffle_chunked<SHC_CB>), dim3((unsigned)n_wg), dim3(256), shc_lds_bytes<SHC_CB>(), st, t->seg_off, t->N, seeds, n_perm,
+                           hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, dig32, dig_out, loc_out);
+        LAUNCH_CHECK();
+        return OFFSIM_OK;
+    }
     if (n_perm > 65535) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: more than 65535 orders of a big-segment table per call%s");
-    hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)n_perm), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)n_perm), dim3(256), 0, st,
                        t->seg_off, t->N, dig32, dig_out, loc_out);
     LAUNCH_CHECK();
     return OFFSIM_OK;
+}
+
+extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
+                                          uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream) {
+    return offsim_shuffle_queues_keys_ws(t, seeds, n_perm, dig32, format, dig_out, loc_out, init_perm_out, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,430 @@
+// shuffle_chunk.hpp -- exact Fisher-Yates for queues that do not fit LDS (states of more than 65536 rows), without random
+// accesses to global memory.
+//
+// The in-place variant of shuffle_wave.hpp keeps such a segment in global memory and pays a random 128-byte line fetched plus a
+// 64-byte sector written back per swap (202 B per swap measured, 3 TB/s of random lines: the memory system's limit).  But two steps
+// of the chain   for i = n-1 .. 1:  j = interval(i);  swap(x[i], x[j])   commute unless the EARLIER one's partner j is the later
+// one's own position or partner: a step never touches a position above its own.  So the positions are cut into chunks of CB, and
+// the chunks are processed top-down, one at a time in LDS:
+//   phase I   the steps ABOVE this chunk whose partner lies in it have left a message each in the chunk's list -- in decreasing
+//             order of their i, which is the order they have to be applied in -- holding (i, j, the value x[i] had at step i):
+//             the chunk takes the value at j (that is x[i]'s final value: it goes into the reply list of i's chunk) and puts the
+//             message's value there;
+//   phase II  the chunk's own steps, hi-1 .. lo: a partner inside the chunk is an ordinary swap in LDS (the grouped apply of
+//             shuffle_wave.hpp: 64 steps at a time, cut into pieces where two of them touch a common position); a partner below
+//             the chunk sends (i, j, x[i]) to the list of j's chunk, and x[i] is final once the reply comes;
+//   then the chunk is stored (4 B per position).  When the chain has run, every chunk is loaded once more, its replies are
+//   scattered into it in LDS, and the finished order goes out as the candidate streams (digest | local-row bits 16.., local-row
+//   low half).
+// All global traffic is sequential: 8 + 8 B per message, 8 + 8 B per reply, 4 + 4 B per position and the 6 B of the streams, against
+// 202 B per swap.  The lists keep their order without sorting: chunks run top-down, a chunk's steps run in decreasing i, and the
+// slot of a message in its list is taken with ONE ds_add_rtn_u32 per group of 64 steps -- the LDS applies the lanes of one such
+// instruction that hit the same address in ascending lane order (= decreasing i; the property scan_rows.hpp relies on as well,
+// offsim_selftest_lds_atomic_order).
+//
+// One PERSISTENT workgroup per CU: it owns one slice of the workspace (message pool + reply pool) and takes (state, rollout) chains
+// from a global counter, longest states first.  Roles as in shuffle_wave.hpp: G x 2 (raw draws), C (the j sequence), A (everything
+// above).  List capacities: a chunk [lo, hi) receives Binomial-sum(m / (i + 1), i >= hi) messages, mean mu = m ln(n / hi); its list
+// holds mu + 8 sqrt(mu) + 128 (a list that overflowed -- 6e-16 per list -- raises OFFSIM_FAULT_SHUFFLE: the call's orders are void).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pcg64_dev.hpp"
+#include "shuffle_wave.hpp"
+
+namespace offsim {
+
+#define SHC_RG 2048u  // raw draws in the ring
+#define SHC_SQ 1024u  // partners in the j ring
+enum { SC_WORK = 11, SC_NCH = 12 };  // further words of the control block (SH_* 0..10)
+
+// messages a chunk list of a segment of n rows has to hold (see above); host and device use the same expression
+__host__ __device__ inline uint32_t shc_list_cap(uint32_t n, uint32_t lo, uint32_t hi) {
+    if (hi >= n) return 128u;
+    const float mu = (float)(hi - lo) * logf((float)n / (float)hi);
+    return (uint32_t)(mu + 8.0f * sqrtf(mu)) + 128u;
+}
+// message pool entries a workgroup needs for segments of up to n rows (host side: sizes the workspace)
+inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
+    uint64_t tot = 0;
+    for (uint32_t lo = 0; lo < n; lo += cb) tot += (uint64_t)shc_list_cap(n, lo, lo + cb < n ? lo + cb : n) + 8u;
+    return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
+}
+
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff, mcap, mcnt, rcnt: KMAX w each][x: CB + 64 w]
+template <uint32_t CB>
+constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 4u * ((1u << 23) / CB) + CB + 64u); }
+
+template <uint32_t CB>
+__global__ void __launch_bounds__(256)
+    k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
+                      const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
+                      int64_t ws_block_words, uint32_t msg_cap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
+                      uint16_t *__restrict__ loc_out) {
+    constexpr uint32_t KMAX = (1u << 23) / CB;
+    constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
+    static_assert((CB & (CB - 1u)) == 0u && JB + 23u + 23u <= 64u, "chunk size: a power of two");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
+    lds_vu32 *ring = ctrl + 16;
+    lds_vu32 *jq = ring + SHC_RG;
+    lds_vu32 *win = jq + SHC_SQ + 64u;
+    lds_vu32 *moff = win + 64u, *mcap = moff + KMAX, *mcnt = mcap + KMAX, *rcnt = mcnt + KMAX;
+    lds_vu32 *x = rcnt + KMAX;  // the chunk; [CB .. CB+63]: one scratch word per lane (lanes without a partner in the chunk)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint64_t *mpool = ws + (int64_t)blockIdx.x * ws_block_words;
+    uint64_t *rpool = mpool + msg_cap;
+    const uint32_t n_work = n_work_seg[0] * (uint32_t)n_perm;
+
+    for (;;) {
+        __syncthreads();  // (the previous chain's last reads of the control block and the lists are done)
+        if (threadIdx.x == 0) ctrl[SC_WORK] = atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t w = ctrl[SC_WORK];
+        if (w >= n_work) return;
+        const uint32_t s = work_seg[w / (uint32_t)n_perm];
+        const int32_t r = (int32_t)(w % (uint32_t)n_perm);
+        const uint32_t beg = seg_off[s], n = seg_off[s + 1] - beg;
+        const uint32_t K = (n + CB - 1u) / CB;
+        uint32_t *xg = dig_out + (int64_t)r * N + beg;  // the chunks between their two visits (32-bit local rows), then the digest stream
+        uint16_t *lc = loc_out + (int64_t)r * N + beg;
+        const uint32_t *dsrc = dig32 + beg;
+        __syncthreads();  // (everyone has read SC_WORK)
+        if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0u;
+        if (threadIdx.x < 64u) win[threadIdx.x] = 0u;
+        for (uint32_t k = threadIdx.x; k < K; k += 256u) {
+            const uint32_t lo = k * CB, hi = lo + CB < n ? lo + CB : n;
+            mcap[k] = shc_list_cap(n, lo, hi);
+            mcnt[k] = 0u;
+            rcnt[k] = 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t off = 0;
+            for (uint32_t k = 0; k < K; k++) {
+                moff[k] = off;
+                off += mcap[k];
+            }
+            if (off > msg_cap) {  // the workspace was sized for shorter segments
+                ctrl[SH_ABORT] = 1u;
+                atomicOr(&g_async_fault, OFFSIM_FAULT_SHUFFLE);
+            }
+        }
+        __syncthreads();
+        if (ctrl[SH_ABORT]) return;
+
+        if (n >= 2u) {
+            if (wave == 0 || wave == 3) {
+                // ---------------- G (two wavefronts, alternate blocks of 128 draws), as in shuffle_wave.hpp
+                const uint32_t g = wave == 0 ? 0u : 1u;
+                const PcgInit p = pcg_seed(seeds[r]);
+                const Jump j128 = pcg_jump(p.inc, 128);
+                U128 st = pcg_apply(pcg_jump(p.inc, 64ull * g + (uint64_t)lane + 1), p.state);
+                uint32_t blk = g, done_blocks = 0, cpub = 0;
+                for (;;) {
+                    bool stop = false;
+                    uint32_t polls = 0;
+                    while ((blk + 1u) * 128u - cpub > SHC_RG) {
+                        shuf_bound(ctrl, polls);
+                        if (sh_ld(ctrl + SH_DONE)) {
+                            stop = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        cpub = sh_ld(ctrl + SH_CPUB);
+                    }
+                    if (stop) break;
+                    const uint64_t o = pcg_output(st);
+                    st = pcg_apply(j128, st);
+                    const uint32_t idx = (blk * 128u + 2u * (uint32_t)lane) & (SHC_RG - 1u);
+                    *(lds_vu64 *)(ring + idx) = o;  // low half first
+                    blk += 2u;
+                    done_blocks++;
+                    sh_st(ctrl + (g ? SH_GEN1 : SH_GEN0), done_blocks);
+                }
+            } else if (wave == 1) {
+                // ---------------- C: the j sequence, 2 x 64 draws per iteration, as in shuffle_wave.hpp
+                uint32_t i = n - 1u, c = 0, avail = 0, fill = 0, tail = 0, c_pub = 0;
+                uint32_t mask = 0xffffffffu >> __builtin_clz(i);
+                int lowpow = (int)((mask >> 1) + 1u);
+                auto wait_draws = [&](uint32_t upto) {
+                    uint32_t polls = 0;
+                    while (upto > avail) {
+                        const uint64_t gg = *(lds_vu64 *)(ctrl + SH_GEN0);
+                        const uint32_t g0 = sh_rfl((uint32_t)gg), g1 = sh_rfl((uint32_t)(gg >> 32));
+                        avail = 128u * (g0 <= g1 ? 2u * g0 : 2u * g1 + 1u);
+                        if (upto > avail) {
+                            shuf_bound(ctrl, polls);
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                };
+                auto wait_room = [&](uint32_t upto) {
+                    uint32_t polls = 0;
+                    while (upto - tail > SHC_SQ) {
+                        tail = sh_ld(ctrl + SH_TAIL);
+                        if (upto - tail > SHC_SQ) {
+                            shuf_bound(ctrl, polls);
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                };
+                auto settle = [&](uint64_t &bal, int &rk, uint32_t v, uint32_t ib) {
+                    uint64_t f = bal & __ballot((int)v > (int)ib - rk);
+                    while (f) {
+                        bal &= ~(1ull << sh_ff1(f));
+                        rk = sh_rank(bal);
+                        f = bal & __ballot((int)v > (int)ib - rk);
+                    }
+                };
+                wait_draws(c + 128u);
+                uint32_t r1 = ring[c + (uint32_t)lane], r2 = ring[c + 64u + (uint32_t)lane];
+                while (i >= 1u) {
+                    wait_draws(c + 256u);
+                    const uint32_t p1 = ring[(c + 128u + (uint32_t)lane) & (SHC_RG - 1u)];
+                    const uint32_t p2 = ring[(c + 192u + (uint32_t)lane) & (SHC_RG - 1u)];
+                    const uint32_t v1 = r1 & mask, v2 = r2 & mask;
+                    uint64_t bal1 = __ballot(v1 <= i);
+                    uint32_t n1 = (uint32_t)__popcll(bal1);
+                    uint32_t i2 = i - n1;
+                    uint64_t bal2 = __ballot((int)v2 <= (int)i2);
+                    int rk1 = sh_rank(bal1), rk2 = sh_rank(bal2);
+                    if (__builtin_expect((bal1 & __ballot((int)v1 > (int)i - rk1)) != 0ull, 0)) {
+                        settle(bal1, rk1, v1, i);
+                        n1 = (uint32_t)__popcll(bal1);
+                        i2 = i - n1;
+                        bal2 = __ballot((int)v2 <= (int)i2);
+                        rk2 = sh_rank(bal2);
+                    }
+                    if (__builtin_expect((bal2 & __ballot((int)v2 > (int)i2 - rk2)) != 0ull, 0)) settle(bal2, rk2, v2, i2);
+                    const uint32_t n2 = (uint32_t)__popcll(bal2);
+                    const int i_new = (int)i2 - (int)n2;
+                    if (__builtin_expect(i_new >= lowpow, 1)) {
+                        wait_room(fill + n1 + n2);
+                        const uint32_t a1 = (int)v1 <= (int)i - rk1 ? ((fill + (uint32_t)rk1) & (SHC_SQ - 1u)) : SHC_SQ + (uint32_t)lane;
+                        const uint32_t a2 = (int)v2 <= (int)i2 - rk2 ? ((fill + n1 + (uint32_t)rk2) & (SHC_SQ - 1u)) : SHC_SQ + (uint32_t)lane;
+                        jq[a1] = v1;
+                        jq[a2] = v2;
+                        fill += n1 + n2;
+                        sh_st(ctrl + SH_FILL, fill);
+                        i = (uint32_t)i_new;
+                        c += 128u;
+                        r1 = p1;
+                        r2 = p2;
+                    } else {
+                        const uint64_t lowm = __ballot((int)i - rk1 < lowpow);
+                        const uint64_t below = (lowm & (0ull - lowm)) - 1ull;
+                        const uint64_t acc = bal1 & below;
+                        const uint32_t na = (uint32_t)__popcll(acc);
+                        wait_room(fill + na);
+                        jq[((acc >> lane) & 1ull) ? ((fill + (uint32_t)rk1) & (SHC_SQ - 1u)) : SHC_SQ + (uint32_t)lane] = v1;
+                        fill += na;
+                        sh_st(ctrl + SH_FILL, fill);
+                        i -= na;
+                        c += (uint32_t)__popcll(below);
+                        if ((int)i < lowpow && i >= 1u) {
+                            mask = 0xffffffffu >> __builtin_clz(i);
+                            lowpow = (int)((mask >> 1) + 1u);
+                        }
+                        wait_draws(c + 128u);
+                        r1 = ring[(c + (uint32_t)lane) & (SHC_RG - 1u)];
+                        r2 = ring[(c + 64u + (uint32_t)lane) & (SHC_RG - 1u)];
+                    }
+                    if (c - c_pub >= 256u) {
+                        c_pub = c;
+                        sh_st(ctrl + SH_CPUB, c);
+                    }
+                }
+                sh_st(ctrl + SH_DONE, 1u);
+            } else {
+                // ---------------- A: the chunks, top-down
+                uint32_t done = 0, fill = 0;
+                // duplicates among the 64 addresses of a group (adr: this lane's word of x, or its scratch word): the lanes that share
+                // a word with an earlier lane start a new piece; returns the piece number of every lane and the number of pieces
+                auto split = [&](uint32_t adr, uint32_t b, uint32_t tg, uint64_t F, uint64_t cuts, uint64_t valid, uint32_t &n_pieces) -> uint32_t {
+                    x[adr] = b;  // take the tags back
+                    if (F) {
+                        const bool lost = tg != (uint32_t)lane;
+                        if (lost) win[tg] = 1u;
+                        const uint32_t wv = win[(uint32_t)lane];
+                        if (lost) win[tg] = 0u;
+                        const uint64_t D = F | __ballot(wv != 0u);
+                        cuts |= D & (D - 1ull);
+                    }
+                    cuts &= valid & ~1ull;  // (a cut in front of lane 0 separates nothing)
+                    n_pieces = (uint32_t)__popcll(cuts) + 1u;
+                    return (uint32_t)sh_rank(cuts) + (uint32_t)((cuts >> lane) & 1ull);
+                };
+                for (int32_t cc = (int32_t)K - 1; cc >= 0; cc--) {
+                    const uint32_t c = (uint32_t)cc, lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
+                    for (uint32_t k = (uint32_t)lane; k < m; k += 64u) x[k] = lo + k;  // identity
+                    // ---- phase I: the messages of the steps above, in list order.  Eight groups of 64 are in flight (one per register pair).
+                    {
+                        const uint32_t cnt = sh_ld(mcnt + c);
+                        const volatile uint64_t *ml = (const volatile uint64_t *)(mpool + sh_ld(moff + c));  // (read past the L1: the pool was another chain's a moment ago)
+                        uint64_t cur[8], nxt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
+                            cur[q] = e < cnt ? ml[e] : 0ull;
+                        }
+                        for (uint32_t b0 = 0; b0 < cnt; b0 += 512u) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t e = b0 + 512u + (uint32_t)q * 64u + (uint32_t)lane;
+                                nxt[q] = e < cnt ? ml[e] : 0ull;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t g0 = b0 + (uint32_t)q * 64u;
+                                if (g0 >= cnt) break;
+                                const bool in = g0 + (uint32_t)lane < cnt;
+                                const uint64_t msg = cur[q];
+                                const uint32_t val = (uint32_t)(msg >> JB) & 0x7fffffu, isrc = (uint32_t)(msg >> (JB + 23u));
+                                const uint32_t adr = in ? ((uint32_t)msg & (CB - 1u)) : CB + (uint32_t)lane;
+                                uint32_t out = x[adr];
+                                x[adr] = (uint32_t)lane;
+                                const uint32_t tg = x[adr];
+                                const uint64_t F = __ballot(tg != (uint32_t)lane);
+                                if (__builtin_expect(F == 0ull, 1)) {
+                                    x[adr] = val;
+                                } else {
+                                    uint32_t n_pieces;
+                                    const uint32_t pid = split(adr, out, tg, F, 0ull, sh_lowmask(cnt - g0), n_pieces);
+                                    for (uint32_t pc = 0; pc < n_pieces; pc++)
+                                        if (pid == pc) {
+                                            out = x[adr];
+                                            x[adr] = val;
+                                        }
+                                }
+                                if (in) {  // x[isrc] is final: the reply
+                                    const uint32_t cs = isrc >> JB;
+                                    const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(rcnt + cs), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    rpool[(uint64_t)cs * CB + slot] = (uint64_t)(isrc & (CB - 1u)) | ((uint64_t)out << JB);
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+                        }
+                    }
+                    // ---- phase II: the chunk's own steps hi-1 .. max(lo, 1), 64 at a time (lane l: step i_top - l)
+                    const uint32_t lo_step = lo ? lo : 1u;
+                    uint32_t i_top = hi - 1u;
+                    while (i_top >= lo_step && hi > lo_step) {
+                        const uint32_t left = i_top - lo_step + 1u, cnt = left < 64u ? left : 64u;
+                        if (fill - done < cnt) {
+                            uint32_t polls = 0;
+                            while (fill - done < cnt) {
+                                fill = sh_ld(ctrl + SH_FILL);
+                                if (fill - done < cnt) {
+                                    shuf_bound(ctrl, polls);
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                            }
+                        }
+                        const uint32_t v = jq[(done + (uint32_t)lane) & (SHC_SQ - 1u)];
+                        done += cnt;
+                        sh_st(ctrl + SH_TAIL, done);  // issued after the read: the entries may be overwritten
+                        const bool in = (uint32_t)lane < cnt;
+                        const uint32_t il = i_top - (uint32_t)lane;  // (meaningless beyond cnt)
+                        const bool intl = in && v >= lo, ext = in && v < lo;
+                        const uint32_t i_low = i_top - cnt;  // the group's steps are i_top .. i_low + 1
+                        // a partner that is the position of a LATER step of the group: that step has to see this swap
+                        const uint64_t confl = __ballot(intl && v < il && v > i_low);
+                        const uint32_t pa = in ? il - lo : CB + (uint32_t)lane;
+                        const uint32_t adr = intl ? v - lo : CB + (uint32_t)lane;
+                        uint32_t a = x[pa], b = x[adr];
+                        x[adr] = (uint32_t)lane;  // tag: lanes with the same partner see one winner
+                        const uint32_t tg = x[adr];
+                        const uint64_t F = __ballot(tg != (uint32_t)lane);
+                        if (__builtin_expect((confl | F) == 0ull, 1)) {
+                            x[adr] = a;
+                            if (intl) x[pa] = b;  // (a self-swap, v == il: both stores write the same value)
+                        } else {
+                            uint64_t cuts = 0, cf = confl;
+                            while (cf) {  // cut in front of the lane that owns the step at the partner's position
+                                cuts |= 1ull << (i_top - sh_rfl((uint32_t)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(cf))));
+                                cf &= cf - 1ull;
+                            }
+                            uint32_t n_pieces;
+                            const uint32_t pid = split(adr, b, tg, F, cuts, sh_lowmask(cnt), n_pieces);
+                            for (uint32_t pc = 0; pc < n_pieces; pc++)
+                                if (pid == pc && in) {
+                                    a = x[pa];
+                                    if (intl) {
+                                        const uint32_t b2 = x[adr];
+                                        x[pa] = b2;
+                                        x[adr] = a;
+                                    }
+                                }
+                        }
+                        if (ext) {  // the partner lies in a lower chunk: (i, j, x[i]) goes to that chunk's list, in step order
+                            const uint32_t d = v >> JB;
+                            const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(mcnt + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (slot < mcap[d]) mpool[moff[d] + slot] = (uint64_t)(v & (CB - 1u)) | ((uint64_t)a << JB) | ((uint64_t)il << (JB + 23u));
+                            else ctrl[SH_ABORT] = 2u;
+                        }
+                        if (__builtin_expect(i_top < cnt, 0)) break;  // (chunk 0 of a segment whose lowest step is 1: i_top would wrap)
+                        i_top -= cnt;
+                    }
+                    if (__builtin_expect(sh_ld(ctrl + SH_ABORT) == 2u, 0)) {  // a list overflowed
+                        if (lane == 0) atomicOr(&g_async_fault, OFFSIM_FAULT_SHUFFLE);
+                        ctrl[SH_ABORT] = 1u;
+                        __builtin_amdgcn_endpgm();
+                    }
+                    for (uint32_t k = (uint32_t)lane; k < m; k += 64u) xg[lo + k] = x[k];  // (positions that wait for a reply hold what they sent)
+                }
+            }
+        } else if (threadIdx.x == 0) {
+            xg[0] = 0u;  // a state with a single row
+        }
+        __syncthreads();
+        __threadfence_block();
+        // ---- the finished order: every chunk once more, with its replies, out as the candidate streams
+        for (uint32_t c = 0; c < K; c++) {
+            const uint32_t lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
+            for (uint32_t k = threadIdx.x; k < m; k += 256u) x[k] = ((volatile uint32_t *)xg)[lo + k];
+            __syncthreads();
+            const uint32_t cnt = rcnt[c];
+            const volatile uint64_t *rl = (const volatile uint64_t *)(rpool + (uint64_t)c * CB);
+            for (uint32_t e = threadIdx.x; e < cnt; e += 256u) {
+                const uint64_t rep = rl[e];
+                x[(uint32_t)rep & (CB - 1u)] = (uint32_t)(rep >> JB);
+            }
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < m; k += 256u) {
+                const uint32_t loc = x[k], h = loc >> 16;
+                xg[lo + k] = dsrc[loc] | ((h & 3u) << 8) | ((h >> 2) << 11);
+                lc[lo + k] = (uint16_t)loc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// The states with more than `above` rows, longest first (the persistent workgroups take them in that order), and the work counter.
+__global__ void __launch_bounds__(256) k_chunk_worklist(const uint32_t *__restrict__ seg_off, int32_t n_slots, uint32_t above,
+                                                        uint32_t *__restrict__ work_seg, uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter) {
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int32_t s = (int32_t)threadIdx.x; s < n_slots; s += 256) {
+        const uint32_t len = seg_off[s + 1] - seg_off[s];
+        if (len <= above) continue;
+        uint32_t rank = 0;  // states that come first: longer ones, and equally long ones with a smaller index
+        for (int32_t q = 0; q < n_slots; q++) {
+            const uint32_t lq = seg_off[q + 1] - seg_off[q];
+            rank += (lq > len || (lq == len && q < s)) ? 1u : 0u;
+        }
+        work_seg[rank] = (uint32_t)s;
+        atomicAdd(&cnt, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n_work_seg[0] = cnt;
+        counter[0] = 0u;
+    }
+}
+
+}  // namespace offsim

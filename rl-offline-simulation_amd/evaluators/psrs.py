@@ -101,8 +101,10 @@ class BatchedPSRS:
                     self._dig_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
                     self._loc_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int16, device=dev)
                 keys, dig32 = self._policy_keys(policy)
-                L.check(L.load().offsim_shuffle_queues_keys(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), self._stream_format(), L.ptr(self._dig_buf),
-                                                            L.ptr(self._loc_buf), L.ptr(self._init_perm_buf), L.stream_ptr()))
+                ws = self._shuffle_workspace()
+                L.check(L.load().offsim_shuffle_queues_keys_ws(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), self._stream_format(), L.ptr(self._dig_buf),
+                                                               L.ptr(self._loc_buf), L.ptr(self._init_perm_buf), L.ptr(ws), 0 if ws is None else ws.numel(),
+                                                               L.stream_ptr()))
                 self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=self._policy_key(policy),
                                      format=self._stream_format())
                 self.state.set_orders(None, 0, self._init_perm_buf, t.N0)
@@ -130,6 +132,25 @@ class BatchedPSRS:
                 self._streams = self._table_order_streams(dig32, self._policy_key(policy))
         else:
             raise ValueError(shuffle)
+
+    def _shuffle_workspace(self):
+        """Workspace of the chunked shuffle (states of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for one persistent
+        workgroup per compute unit, or for as many as half of the free HBM holds; None (the in-place shuffle) when the table has no
+        such state, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit."""
+        t = self.table
+        if t.max_seg <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
+            return None
+        if getattr(self, "_ws", None) is None:
+            lib = L.load()
+            cus = torch.cuda.get_device_properties(t.device).multi_processor_count
+            one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
+            head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
+            free = torch.cuda.mem_get_info(t.device)[0]
+            n = min(cus, max(0, (free // 2 - head) // max(one - head, 1)))
+            if one <= 0 or n < 1:
+                return None
+            self._ws = torch.empty(int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), int(n))), dtype=torch.uint8, device=t.device)
+        return self._ws
 
     # ---- candidate streams for the row-packed scan ----
     def _streams_apply(self, policy):
