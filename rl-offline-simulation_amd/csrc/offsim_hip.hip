@@ -356,11 +356,15 @@ __global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ s
 
 // Workspace of the chunked shuffle (shuffle_chunk.hpp): header (work counter, work list) + one message pool and one reply pool per
 // persistent workgroup, sized for the table's longest state.
-#define SHC_CB 32768u
+// Chunk size: OFFSIM_SHUFFLE_CHUNK = 16384 (default: two persistent workgroups per CU), 32768 (one) or 8192 (three).
 #define SHC_HEADER_BYTES 4096
+static uint32_t shc_cb() {
+    static const int v = getenv("OFFSIM_SHUFFLE_CHUNK") ? atoi(getenv("OFFSIM_SHUFFLE_CHUNK")) : 0;
+    return v == 8192 ? 8192u : v == 32768 ? 32768u : 16384u;
+}
 static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
-    const uint32_t n = (uint32_t)t->max_seg;
-    const uint64_t msg = shc_pool_entries(n, SHC_CB), rep = (uint64_t)((n + SHC_CB - 1u) / SHC_CB) * SHC_CB;
+    const uint32_t n = (uint32_t)t->max_seg, cb = shc_cb();
+    const uint64_t msg = shc_pool_entries(n, cb), rep = (uint64_t)((n + cb - 1u) / cb) * cb;
     if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
     return (int64_t)(msg + rep);
 }
@@ -391,7 +395,8 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
         n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n_wg = n_wg > cus ? cus : n_wg;  // one persistent workgroup per CU (its chunk takes the CU's LDS)
+        const int64_t per_cu = shc_cb() == 8192u ? 3 : shc_cb() == 16384u ? 2 : 1;  // persistent workgroups per CU (what their chunks leave of its LDS)
+        n_wg = n_wg > cus * per_cu ? cus * per_cu : n_wg;
     }
     const bool chunked = n_wg >= 1;
     int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
@@ -400,9 +405,17 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
         uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
         hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, SHUF_CAP16, hdr + 64, hdr + 1, hdr);
         LAUNCH_CHECK();
-        HIP_TRY(allow_big_lds((k_shuffle_chunked<SHC_CB>), 160 * 1024));
-        hipLaunchKernelGGL((k_shuffle_chunked<SHC_CB>), dim3((unsigned)n_wg), dim3(256), shc_lds_bytes<SHC_CB>(), st, t->seg_off, t->N, seeds, n_perm,
-                           hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, dig32, dig_out, loc_out);
+#define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
+    do {                                                                                                                                \
+        HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
+        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), (shc_lds_bytes<CB, RG, SQ>()), st, t->seg_off, t->N, \
+                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, dig32,    \
+                           dig_out, loc_out);                                                                                           \
+    } while (0)
+        if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 1024u, 512u);
+        else if (shc_cb() == 8192u) SHC_LAUNCH(8192u, 1024u, 512u);
+        else SHC_LAUNCH(32768u, 2048u, 1024u);
+#undef SHC_LAUNCH
         LAUNCH_CHECK();
         return OFFSIM_OK;
     }

@@ -35,8 +35,6 @@
 
 namespace offsim {
 
-#define SHC_RG 2048u  // raw draws in the ring
-#define SHC_SQ 1024u  // partners in the j ring
 enum { SC_WORK = 11, SC_NCH = 12 };  // further words of the control block (SH_* 0..10)
 
 // messages a chunk list of a segment of n rows has to hold (see above); host and device use the same expression
@@ -52,11 +50,12 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
 }
 
-// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff, mcap, mcnt, rcnt: KMAX w each][x: CB + 64 w]
-template <uint32_t CB>
-constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 4u * ((1u << 23) / CB) + CB + 64u); }
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: KMAX + 1 w][mcnt, rcnt: KMAX w each][x: CB + 64 w]
+// (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
+template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
+constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * ((1u << 23) / CB) + 16u + CB + 64u); }
 
-template <uint32_t CB>
+template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
 __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
@@ -70,7 +69,7 @@ __global__ void __launch_bounds__(256)
     lds_vu32 *ring = ctrl + 16;
     lds_vu32 *jq = ring + SHC_RG;
     lds_vu32 *win = jq + SHC_SQ + 64u;
-    lds_vu32 *moff = win + 64u, *mcap = moff + KMAX, *mcnt = mcap + KMAX, *rcnt = mcnt + KMAX;
+    lds_vu32 *moff = win + 64u, *mcnt = moff + KMAX + 16u, *rcnt = mcnt + KMAX;  // (moff[K] = the end of the last list)
     lds_vu32 *x = rcnt + KMAX;  // the chunk; [CB .. CB+63]: one scratch word per lane (lanes without a partner in the chunk)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint64_t *mpool = ws + (int64_t)blockIdx.x * ws_block_words;
@@ -95,17 +94,19 @@ __global__ void __launch_bounds__(256)
         if (threadIdx.x < 64u) win[threadIdx.x] = 0u;
         for (uint32_t k = threadIdx.x; k < K; k += 256u) {
             const uint32_t lo = k * CB, hi = lo + CB < n ? lo + CB : n;
-            mcap[k] = shc_list_cap(n, lo, hi);
+            moff[k + 1u] = shc_list_cap(n, lo, hi);
             mcnt[k] = 0u;
             rcnt[k] = 0u;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t off = 0;
-            for (uint32_t k = 0; k < K; k++) {
+            for (uint32_t k = 0; k < K; k++) {  // capacities -> offsets
+                const uint32_t cap = moff[k + 1u];
                 moff[k] = off;
-                off += mcap[k];
+                off += cap;
             }
+            moff[K] = off;
             if (off > msg_cap) {  // the workspace was sized for shorter segments
                 ctrl[SH_ABORT] = 1u;
                 atomicOr(&g_async_fault, OFFSIM_FAULT_SHUFFLE);
@@ -240,6 +241,12 @@ __global__ void __launch_bounds__(256)
             } else {
                 // ---------------- A: the chunks, top-down
                 uint32_t done = 0, fill = 0;
+#ifdef SHC_PROF
+                uint64_t pf_i = 0, pf_ii = 0, pf_io = 0, pf_wait = 0, pf_t = __builtin_amdgcn_s_memtime();
+#define SHC_PH(x) { const uint64_t _n = __builtin_amdgcn_s_memtime(); x += _n - pf_t; pf_t = _n; }
+#else
+#define SHC_PH(x)
+#endif
                 // duplicates among the 64 addresses of a group (adr: this lane's word of x, or its scratch word): the lanes that share
                 // a word with an earlier lane start a new piece; returns the piece number of every lane and the number of pieces
                 auto split = [&](uint32_t adr, uint32_t b, uint32_t tg, uint64_t F, uint64_t cuts, uint64_t valid, uint32_t &n_pieces) -> uint32_t {
@@ -259,10 +266,12 @@ __global__ void __launch_bounds__(256)
                 for (int32_t cc = (int32_t)K - 1; cc >= 0; cc--) {
                     const uint32_t c = (uint32_t)cc, lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
                     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) x[k] = lo + k;  // identity
+                    SHC_PH(pf_io);
                     // ---- phase I: the messages of the steps above, in list order.  Eight groups of 64 are in flight (one per register pair).
                     {
                         const uint32_t cnt = sh_ld(mcnt + c);
-                        const volatile uint64_t *ml = (const volatile uint64_t *)(mpool + sh_ld(moff + c));  // (read past the L1: the pool was another chain's a moment ago)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the pool was another chain's a moment ago: nothing stale from the L1)
+                        const uint64_t *ml = mpool + sh_ld(moff + c);
                         uint64_t cur[8], nxt[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
@@ -308,12 +317,14 @@ __global__ void __launch_bounds__(256)
                             for (int q = 0; q < 8; q++) cur[q] = nxt[q];
                         }
                     }
+                    SHC_PH(pf_i);
                     // ---- phase II: the chunk's own steps hi-1 .. max(lo, 1), 64 at a time (lane l: step i_top - l)
                     const uint32_t lo_step = lo ? lo : 1u;
                     uint32_t i_top = hi - 1u;
                     while (i_top >= lo_step && hi > lo_step) {
                         const uint32_t left = i_top - lo_step + 1u, cnt = left < 64u ? left : 64u;
                         if (fill - done < cnt) {
+                            SHC_PH(pf_ii);
                             uint32_t polls = 0;
                             while (fill - done < cnt) {
                                 fill = sh_ld(ctrl + SH_FILL);
@@ -322,6 +333,7 @@ __global__ void __launch_bounds__(256)
                                     __builtin_amdgcn_s_sleep(1);
                                 }
                             }
+                            SHC_PH(pf_wait);
                         }
                         const uint32_t v = jq[(done + (uint32_t)lane) & (SHC_SQ - 1u)];
                         done += cnt;
@@ -362,44 +374,95 @@ __global__ void __launch_bounds__(256)
                         if (ext) {  // the partner lies in a lower chunk: (i, j, x[i]) goes to that chunk's list, in step order
                             const uint32_t d = v >> JB;
                             const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(mcnt + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (slot < mcap[d]) mpool[moff[d] + slot] = (uint64_t)(v & (CB - 1u)) | ((uint64_t)a << JB) | ((uint64_t)il << (JB + 23u));
+                            const uint32_t mo = moff[d];
+                            if (slot < moff[d + 1u] - mo) mpool[mo + slot] = (uint64_t)(v & (CB - 1u)) | ((uint64_t)a << JB) | ((uint64_t)il << (JB + 23u));
                             else ctrl[SH_ABORT] = 2u;
                         }
                         if (__builtin_expect(i_top < cnt, 0)) break;  // (chunk 0 of a segment whose lowest step is 1: i_top would wrap)
                         i_top -= cnt;
                     }
+                    SHC_PH(pf_ii);
                     if (__builtin_expect(sh_ld(ctrl + SH_ABORT) == 2u, 0)) {  // a list overflowed
                         if (lane == 0) atomicOr(&g_async_fault, OFFSIM_FAULT_SHUFFLE);
                         ctrl[SH_ABORT] = 1u;
                         __builtin_amdgcn_endpgm();
                     }
                     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) xg[lo + k] = x[k];  // (positions that wait for a reply hold what they sent)
+                    SHC_PH(pf_io);
                 }
+#ifdef SHC_PROF
+                if (w == 0u && lane == 0) {
+                    uint64_t *o = (uint64_t *)(counter + 16);
+                    o[0] = pf_i, o[1] = pf_ii, o[2] = pf_io, o[3] = pf_wait;
+                }
+#endif
             }
         } else if (threadIdx.x == 0) {
             xg[0] = 0u;  // a state with a single row
         }
         __syncthreads();
         __threadfence_block();
-        // ---- the finished order: every chunk once more, with its replies, out as the candidate streams
+        // ---- the finished order: every chunk once more, with its replies, out as the candidate streams.  Eight independent loads per
+        // thread and turn (the gathers from the state's slice of dig32 are random 4-byte reads: latency, not bandwidth).
+#ifdef SHC_PROF
+        const uint64_t pf_f0 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the chunks and replies were stored by wavefront A: nothing stale from the L1)
         for (uint32_t c = 0; c < K; c++) {
             const uint32_t lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
-            for (uint32_t k = threadIdx.x; k < m; k += 256u) x[k] = ((volatile uint32_t *)xg)[lo + k];
-            __syncthreads();
-            const uint32_t cnt = rcnt[c];
-            const volatile uint64_t *rl = (const volatile uint64_t *)(rpool + (uint64_t)c * CB);
-            for (uint32_t e = threadIdx.x; e < cnt; e += 256u) {
-                const uint64_t rep = rl[e];
-                x[(uint32_t)rep & (CB - 1u)] = (uint32_t)(rep >> JB);
+            for (uint32_t k0 = threadIdx.x; k0 < m; k0 += 2048u) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u;
+                    v[u] = k < m ? xg[lo + k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u;
+                    if (k < m) x[k] = v[u];
+                }
             }
             __syncthreads();
-            for (uint32_t k = threadIdx.x; k < m; k += 256u) {
-                const uint32_t loc = x[k], h = loc >> 16;
-                xg[lo + k] = dsrc[loc] | ((h & 3u) << 8) | ((h >> 2) << 11);
-                lc[lo + k] = (uint16_t)loc;
+            const uint32_t cnt = rcnt[c];
+            const uint64_t *rl = rpool + (uint64_t)c * CB;
+            for (uint32_t e0 = threadIdx.x; e0 < cnt; e0 += 2048u) {
+                uint64_t rep[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t e = e0 + 256u * (uint32_t)u;
+                    rep[u] = e < cnt ? rl[e] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t e = e0 + 256u * (uint32_t)u;
+                    if (e < cnt) x[(uint32_t)rep[u] & (CB - 1u)] = (uint32_t)(rep[u] >> JB);
+                }
+            }
+            __syncthreads();
+            for (uint32_t k0 = threadIdx.x; k0 < m; k0 += 2048u) {
+                uint32_t loc[8], dgv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u;
+                    loc[u] = k < m ? x[k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) dgv[u] = dsrc[loc[u]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t k = k0 + 256u * (uint32_t)u, h = loc[u] >> 16;
+                    if (k < m) {
+                        xg[lo + k] = dgv[u] | ((h & 3u) << 8) | ((h >> 2) << 11);
+                        lc[lo + k] = (uint16_t)loc[u];
+                    }
+                }
             }
             __syncthreads();
         }
+#ifdef SHC_PROF
+        if (w == 0u && threadIdx.x == 0) ((uint64_t *)(counter + 16))[4] = __builtin_amdgcn_s_memtime() - pf_f0;
+#endif
     }
 }
 

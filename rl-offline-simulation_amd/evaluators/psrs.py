@@ -142,7 +142,7 @@ class BatchedPSRS:
             return None
         if getattr(self, "_ws", None) is None:
             lib = L.load()
-            cus = torch.cuda.get_device_properties(t.device).multi_processor_count
+            cus = torch.cuda.get_device_properties(t.device).multi_processor_count * {"8192": 3, "32768": 1}.get(os.environ.get("OFFSIM_SHUFFLE_CHUNK"), 2)
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
             head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
             free = torch.cuda.mem_get_info(t.device)[0]
