@@ -356,17 +356,17 @@ __global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ s
 
 // Workspace of the chunked shuffle (shuffle_chunk.hpp): header (work counter, work list) + one message pool and one reply pool per
 // persistent workgroup, sized for the table's longest state.
-// Chunk size: OFFSIM_SHUFFLE_CHUNK = 16384 (default: two persistent workgroups per CU), 32768 (one) or 8192 (three).
+// Chunk size: OFFSIM_SHUFFLE_CHUNK = 8192 (default: two persistent workgroups per CU) or 16384 (one).
 #define SHC_HEADER_BYTES 4096
 static uint32_t shc_cb() {
     static const int v = getenv("OFFSIM_SHUFFLE_CHUNK") ? atoi(getenv("OFFSIM_SHUFFLE_CHUNK")) : 0;
-    return v == 8192 ? 8192u : v == 32768 ? 32768u : 16384u;
+    return v == 16384 ? 16384u : 8192u;
 }
 static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
     const uint32_t n = (uint32_t)t->max_seg, cb = shc_cb();
     const uint64_t msg = shc_pool_entries(n, cb), rep = (uint64_t)((n + cb - 1u) / cb) * cb;
     if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
-    return (int64_t)(msg + rep);
+    return (int64_t)(msg + (msg + 1u) / 2u + rep);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
 }
 extern "C" int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_blocks) {
     if (!t || n_blocks < 1 || t->max_seg <= (int64_t)SHUF_CAP16 || t->max_seg > (1ll << 23) || t->n_slots > 1000) return 0;
@@ -390,12 +390,12 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     // otherwise in place in global memory (the state's slice of dig_out) and one more pass that turns the order into streams
     uint32_t msg_cap = 0;
     int64_t n_wg = 0, words = 0;
+    int dev = 0, cus = 256;
     if (big && workspace && ((uintptr_t)workspace & 7u) == 0) {
         words = shc_block_words(t, &msg_cap);
         n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
-        int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t per_cu = shc_cb() == 8192u ? 3 : shc_cb() == 16384u ? 2 : 1;  // persistent workgroups per CU (what their chunks leave of its LDS)
+        const int64_t per_cu = shc_cb() == 8192u ? 2 : 1;  // persistent workgroups per CU (what their chunks leave of its LDS)
         n_wg = n_wg > cus * per_cu ? cus * per_cu : n_wg;
     }
     const bool chunked = n_wg >= 1;
@@ -405,16 +405,16 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
         uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
         hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, SHUF_CAP16, hdr + 64, hdr + 1, hdr);
         LAUNCH_CHECK();
+        const uint32_t role_turn = getenv("OFFSIM_SHUFFLE_TURN") ? (uint32_t)atoi(getenv("OFFSIM_SHUFFLE_TURN")) : (uint32_t)cus;
 #define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
     do {                                                                                                                                \
         HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
         hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), (shc_lds_bytes<CB, RG, SQ>()), st, t->seg_off, t->N, \
-                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, dig32,    \
+                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, role_turn, dig32,    \
                            dig_out, loc_out);                                                                                           \
     } while (0)
-        if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 1024u, 512u);
-        else if (shc_cb() == 8192u) SHC_LAUNCH(8192u, 1024u, 512u);
-        else SHC_LAUNCH(32768u, 2048u, 1024u);
+        if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
+        else SHC_LAUNCH(8192u, 1024u, 512u);
 #undef SHC_LAUNCH
         LAUNCH_CHECK();
         return OFFSIM_OK;

@@ -43,6 +43,8 @@ __host__ __device__ inline uint32_t shc_list_cap(uint32_t n, uint32_t lo, uint32
     const float mu = (float)(hi - lo) * logf((float)n / (float)hi);
     return (uint32_t)(mu + 8.0f * sqrtf(mu)) + 128u;
 }
+// bits 16.. of a local row where the digest word of stream format B carries them (bits 8, 9 and 11..15)
+__host__ __device__ inline uint32_t shc_hi_bits(uint32_t loc) { return (((loc >> 16) & 3u) << 8) | ((loc >> 18) << 11); }
 // message pool entries a workgroup needs for segments of up to n rows (host side: sizes the workspace)
 inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     uint64_t tot = 0;
@@ -50,30 +52,39 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
 }
 
-// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: KMAX + 1 w][mcnt, rcnt: KMAX w each][x: CB + 64 w]
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: KMAX + 1 w][mcnt, rcnt: KMAX w each][xd: CB + 64 w][xl: CB + 64 halfwords]
 // (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
-constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * ((1u << 23) / CB) + 16u + CB + 64u); }
+constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * ((1u << 23) / CB) + 16u) + 6u * (CB + 64u); }
 
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
 __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
-                      int64_t ws_block_words, uint32_t msg_cap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
+                      int64_t ws_block_words, uint32_t msg_cap, uint32_t role_turn, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
                       uint16_t *__restrict__ loc_out) {
     constexpr uint32_t KMAX = (1u << 23) / CB;
     constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
-    static_assert((CB & (CB - 1u)) == 0u && JB + 23u + 23u <= 64u, "chunk size: a power of two");
+    static_assert((CB & (CB - 1u)) == 0u && JB <= 15u, "chunk size: a power of two, at most 32768 (a position inside its chunk travels in 15 bits)");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
     lds_vu32 *jq = ring + SHC_RG;
     lds_vu32 *win = jq + SHC_SQ + 64u;
     lds_vu32 *moff = win + 64u, *mcnt = moff + KMAX + 16u, *rcnt = mcnt + KMAX;  // (moff[K] = the end of the last list)
-    lds_vu32 *x = rcnt + KMAX;  // the chunk; [CB .. CB+63]: one scratch word per lane (lanes without a partner in the chunk)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    uint64_t *mpool = ws + (int64_t)blockIdx.x * ws_block_words;
-    uint64_t *rpool = mpool + msg_cap;
+    // the chunk: one RECORD per position, in the streams' own layout -- xd = the digest word (digest | bits 16.. of the local row),
+    // xl = the local row's low half; entries [CB .. CB+63]: one scratch entry per lane (lanes without a partner in the chunk)
+    lds_vu32 *xd = rcnt + KMAX;
+    lds_vu16 *xl = (lds_vu16 *)(xd + CB + 64u);
+    // Roles by wavefront: 0 and 3 = G, 1 = C, 2 = A.  Two workgroups share a CU, and a workgroup's wavefront k runs on SIMD k: every
+    // other workgroup (the second one of each CU: workgroups are handed out CU by CU) turns its roles by two, so that the two A
+    // wavefronts -- the ones bound by what they issue -- and the two C wavefronts sit on different SIMDs.
+    const int wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wave = (wave_hw + (int)(((blockIdx.x / role_turn) & 1u) << 1)) & 3;
+    // this workgroup's pools: messages as {record | j inside its chunk << 48} + {i}, replies as {record | i inside its chunk << 48}
+    uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
+    uint32_t *m32 = (uint32_t *)(m64 + msg_cap);
+    uint64_t *rpool = m64 + msg_cap + (msg_cap + 1u) / 2u;
     const uint32_t n_work = n_work_seg[0] * (uint32_t)n_perm;
 
     for (;;) {
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(256)
         const int32_t r = (int32_t)(w % (uint32_t)n_perm);
         const uint32_t beg = seg_off[s], n = seg_off[s + 1] - beg;
         const uint32_t K = (n + CB - 1u) / CB;
-        uint32_t *xg = dig_out + (int64_t)r * N + beg;  // the chunks between their two visits (32-bit local rows), then the digest stream
+        uint32_t *dg = dig_out + (int64_t)r * N + beg;
         uint16_t *lc = loc_out + (int64_t)r * N + beg;
         const uint32_t *dsrc = dig32 + beg;
         __syncthreads();  // (everyone has read SC_WORK)
@@ -247,10 +258,10 @@ __global__ void __launch_bounds__(256)
 #else
 #define SHC_PH(x)
 #endif
-                // duplicates among the 64 addresses of a group (adr: this lane's word of x, or its scratch word): the lanes that share
-                // a word with an earlier lane start a new piece; returns the piece number of every lane and the number of pieces
+                // duplicates among the 64 addresses of a group (adr: this lane's entry of the chunk, or its scratch entry): the lanes that
+                // share an entry with an earlier lane start a new piece; returns the piece number of every lane and the number of pieces
                 auto split = [&](uint32_t adr, uint32_t b, uint32_t tg, uint64_t F, uint64_t cuts, uint64_t valid, uint32_t &n_pieces) -> uint32_t {
-                    x[adr] = b;  // take the tags back
+                    xd[adr] = b;  // take the tags back
                     if (F) {
                         const bool lost = tg != (uint32_t)lane;
                         if (lost) win[tg] = 1u;
@@ -265,24 +276,44 @@ __global__ void __launch_bounds__(256)
                 };
                 for (int32_t cc = (int32_t)K - 1; cc >= 0; cc--) {
                     const uint32_t c = (uint32_t)cc, lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
-                    for (uint32_t k = (uint32_t)lane; k < m; k += 64u) x[k] = lo + k;  // identity
+                    // identity: position lo + k holds the record of local row lo + k (its digest comes in sequentially: 4 B per row)
+                    for (uint32_t k0 = (uint32_t)lane; k0 < m; k0 += 2048u) {
+                        uint32_t dv[32];
+#pragma unroll
+                        for (int u = 0; u < 32; u++) {
+                            const uint32_t k = k0 + 64u * (uint32_t)u;
+                            dv[u] = k < m ? dsrc[lo + k] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 32; u++) {
+                            const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
+                            if (k < m) {
+                                xd[k] = dv[u] | shc_hi_bits(loc);
+                                xl[k] = (uint16_t)loc;
+                            }
+                        }
+                    }
                     SHC_PH(pf_io);
-                    // ---- phase I: the messages of the steps above, in list order.  Eight groups of 64 are in flight (one per register pair).
+                    // ---- phase I: the messages of the steps above, in list order.  Eight groups of 64 are in flight (one per register set).
                     {
-                        const uint32_t cnt = sh_ld(mcnt + c);
+                        const uint32_t cnt = sh_ld(mcnt + c), mo = sh_ld(moff + c);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the pool was another chain's a moment ago: nothing stale from the L1)
-                        const uint64_t *ml = mpool + sh_ld(moff + c);
+                        const uint64_t *ml = m64 + mo;
+                        const uint32_t *mi = m32 + mo;
                         uint64_t cur[8], nxt[8];
+                        uint32_t curi[8], nxti[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
                             const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
                             cur[q] = e < cnt ? ml[e] : 0ull;
+                            curi[q] = e < cnt ? mi[e] : 0u;
                         }
                         for (uint32_t b0 = 0; b0 < cnt; b0 += 512u) {
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
                                 const uint32_t e = b0 + 512u + (uint32_t)q * 64u + (uint32_t)lane;
                                 nxt[q] = e < cnt ? ml[e] : 0ull;
+                                nxti[q] = e < cnt ? mi[e] : 0u;
                             }
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
@@ -290,31 +321,37 @@ __global__ void __launch_bounds__(256)
                                 if (g0 >= cnt) break;
                                 const bool in = g0 + (uint32_t)lane < cnt;
                                 const uint64_t msg = cur[q];
-                                const uint32_t val = (uint32_t)(msg >> JB) & 0x7fffffu, isrc = (uint32_t)(msg >> (JB + 23u));
-                                const uint32_t adr = in ? ((uint32_t)msg & (CB - 1u)) : CB + (uint32_t)lane;
-                                uint32_t out = x[adr];
-                                x[adr] = (uint32_t)lane;
-                                const uint32_t tg = x[adr];
+                                const uint32_t vd = (uint32_t)msg, vl = (uint32_t)(msg >> 32) & 0xffffu, isrc = curi[q];
+                                const uint32_t adr = in ? (uint32_t)(msg >> 48) : CB + (uint32_t)lane;
+                                uint32_t od = xd[adr], ol = xl[adr];
+                                xd[adr] = (uint32_t)lane;
+                                const uint32_t tg = xd[adr];
                                 const uint64_t F = __ballot(tg != (uint32_t)lane);
                                 if (__builtin_expect(F == 0ull, 1)) {
-                                    x[adr] = val;
+                                    xd[adr] = vd;
+                                    xl[adr] = (uint16_t)vl;
                                 } else {
                                     uint32_t n_pieces;
-                                    const uint32_t pid = split(adr, out, tg, F, 0ull, sh_lowmask(cnt - g0), n_pieces);
+                                    const uint32_t pid = split(adr, od, tg, F, 0ull, sh_lowmask(cnt - g0), n_pieces);
                                     for (uint32_t pc = 0; pc < n_pieces; pc++)
                                         if (pid == pc) {
-                                            out = x[adr];
-                                            x[adr] = val;
+                                            od = xd[adr];
+                                            ol = xl[adr];
+                                            xd[adr] = vd;
+                                            xl[adr] = (uint16_t)vl;
                                         }
                                 }
-                                if (in) {  // x[isrc] is final: the reply
+                                if (in) {  // what was there is the final entry of position isrc: the reply
                                     const uint32_t cs = isrc >> JB;
                                     const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(rcnt + cs), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    rpool[(uint64_t)cs * CB + slot] = (uint64_t)(isrc & (CB - 1u)) | ((uint64_t)out << JB);
+                                    rpool[(uint64_t)cs * CB + slot] = (uint64_t)od | ((uint64_t)ol << 32) | ((uint64_t)(isrc & (CB - 1u)) << 48);
                                 }
                             }
 #pragma unroll
-                            for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+                            for (int q = 0; q < 8; q++) {
+                                cur[q] = nxt[q];
+                                curi[q] = nxti[q];
+                            }
                         }
                     }
                     SHC_PH(pf_i);
@@ -342,44 +379,57 @@ __global__ void __launch_bounds__(256)
                         const uint32_t il = i_top - (uint32_t)lane;  // (meaningless beyond cnt)
                         const bool intl = in && v >= lo, ext = in && v < lo;
                         const uint32_t i_low = i_top - cnt;  // the group's steps are i_top .. i_low + 1
-                        // a partner that is the position of a LATER step of the group: that step has to see this swap
-                        const uint64_t confl = __ballot(intl && v < il && v > i_low);
                         const uint32_t pa = in ? il - lo : CB + (uint32_t)lane;
-                        const uint32_t adr = intl ? v - lo : CB + (uint32_t)lane;
-                        uint32_t a = x[pa], b = x[adr];
-                        x[adr] = (uint32_t)lane;  // tag: lanes with the same partner see one winner
-                        const uint32_t tg = x[adr];
-                        const uint64_t F = __ballot(tg != (uint32_t)lane);
-                        if (__builtin_expect((confl | F) == 0ull, 1)) {
-                            x[adr] = a;
-                            if (intl) x[pa] = b;  // (a self-swap, v == il: both stores write the same value)
-                        } else {
-                            uint64_t cuts = 0, cf = confl;
-                            while (cf) {  // cut in front of the lane that owns the step at the partner's position
-                                cuts |= 1ull << (i_top - sh_rfl((uint32_t)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(cf))));
-                                cf &= cf - 1ull;
-                            }
-                            uint32_t n_pieces;
-                            const uint32_t pid = split(adr, b, tg, F, cuts, sh_lowmask(cnt), n_pieces);
-                            for (uint32_t pc = 0; pc < n_pieces; pc++)
-                                if (pid == pc && in) {
-                                    a = x[pa];
-                                    if (intl) {
-                                        const uint32_t b2 = x[adr];
-                                        x[pa] = b2;
-                                        x[adr] = a;
-                                    }
+                        uint32_t ad = xd[pa], al = xl[pa];
+                        if (__ballot(intl) != 0ull) {  // (a group whose partners all lie below the chunk only sends)
+                            // a partner that is the position of a LATER step of the group: that step has to see this swap
+                            const uint64_t confl = __ballot(intl && v < il && v > i_low);
+                            const uint32_t adr = intl ? v - lo : CB + (uint32_t)lane;
+                            const uint32_t bd = xd[adr], bl = xl[adr];
+                            xd[adr] = (uint32_t)lane;  // tag: lanes with the same partner see one winner
+                            const uint32_t tg = xd[adr];
+                            const uint64_t F = __ballot(tg != (uint32_t)lane);
+                            if (__builtin_expect((confl | F) == 0ull, 1)) {
+                                xd[adr] = ad;
+                                xl[adr] = (uint16_t)al;
+                                if (intl) {  // (a self-swap, v == il: both pairs of stores write the same record)
+                                    xd[pa] = bd;
+                                    xl[pa] = (uint16_t)bl;
                                 }
+                            } else {
+                                uint64_t cuts = 0, cf = confl;
+                                while (cf) {  // cut in front of the lane that owns the step at the partner's position
+                                    cuts |= 1ull << (i_top - sh_rfl((uint32_t)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(cf))));
+                                    cf &= cf - 1ull;
+                                }
+                                uint32_t n_pieces;
+                                const uint32_t pid = split(adr, bd, tg, F, cuts, sh_lowmask(cnt), n_pieces);
+                                for (uint32_t pc = 0; pc < n_pieces; pc++)
+                                    if (pid == pc && in) {
+                                        ad = xd[pa];
+                                        al = xl[pa];
+                                        if (intl) {
+                                            const uint32_t b2d = xd[adr], b2l = xl[adr];
+                                            xd[pa] = b2d;
+                                            xl[pa] = (uint16_t)b2l;
+                                            xd[adr] = ad;
+                                            xl[adr] = (uint16_t)al;
+                                        }
+                                    }
+                            }
                         }
-                        if (ext) {  // the partner lies in a lower chunk: (i, j, x[i]) goes to that chunk's list, in step order
+                        if (ext) {  // the partner lies in a lower chunk: (i, j, the record at i) goes to that chunk's list, in step order
                             const uint32_t d = v >> JB;
                             const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(mcnt + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const uint32_t mo = moff[d];
-                            if (slot < moff[d + 1u] - mo) mpool[mo + slot] = (uint64_t)(v & (CB - 1u)) | ((uint64_t)a << JB) | ((uint64_t)il << (JB + 23u));
-                            else ctrl[SH_ABORT] = 2u;
+                            if (slot < moff[d + 1u] - mo) {
+                                m64[mo + slot] = (uint64_t)ad | ((uint64_t)al << 32) | ((uint64_t)(v & (CB - 1u)) << 48);
+                                m32[mo + slot] = il;
+                            } else {
+                                ctrl[SH_ABORT] = 2u;
+                            }
                         }
-                        if (__builtin_expect(i_top < cnt, 0)) break;  // (chunk 0 of a segment whose lowest step is 1: i_top would wrap)
-                        i_top -= cnt;
+                        i_top -= cnt;  // (never below lo - 1, and chunk 0 ends at step 1: no wrap)
                     }
                     SHC_PH(pf_ii);
                     if (__builtin_expect(sh_ld(ctrl + SH_ABORT) == 2u, 0)) {  // a list overflowed
@@ -387,7 +437,24 @@ __global__ void __launch_bounds__(256)
                         ctrl[SH_ABORT] = 1u;
                         __builtin_amdgcn_endpgm();
                     }
-                    for (uint32_t k = (uint32_t)lane; k < m; k += 64u) xg[lo + k] = x[k];  // (positions that wait for a reply hold what they sent)
+                    // the chunk goes out in the streams' own layout (positions that wait for a reply hold what they sent)
+                    for (uint32_t k0 = (uint32_t)lane; k0 < m; k0 += 512u) {
+                        uint32_t vd[8], vl[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const uint32_t k = k0 + 64u * (uint32_t)u;
+                            vd[u] = xd[k < m ? k : 0u];
+                            vl[u] = xl[k < m ? k : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const uint32_t k = k0 + 64u * (uint32_t)u;
+                            if (k < m) {
+                                dg[lo + k] = vd[u];
+                                lc[lo + k] = (uint16_t)vl[u];
+                            }
+                        }
+                    }
                     SHC_PH(pf_io);
                 }
 #ifdef SHC_PROF
@@ -397,34 +464,40 @@ __global__ void __launch_bounds__(256)
                 }
 #endif
             }
-        } else if (threadIdx.x == 0) {
-            xg[0] = 0u;  // a state with a single row
+        } else if (threadIdx.x == 0) {  // a state with a single row
+            dg[0] = dsrc[0];
+            lc[0] = 0;
         }
         __syncthreads();
-        __threadfence_block();
-        // ---- the finished order: every chunk once more, with its replies, out as the candidate streams.  Eight independent loads per
-        // thread and turn (the gathers from the state's slice of dig32 are random 4-byte reads: latency, not bandwidth).
 #ifdef SHC_PROF
         const uint64_t pf_f0 = __builtin_amdgcn_s_memtime();
 #endif
+        // ---- the replies: every chunk that sent messages once more, its replies scattered into it in LDS.  Eight independent loads per
+        // thread and turn.
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the chunks and replies were stored by wavefront A: nothing stale from the L1)
-        for (uint32_t c = 0; c < K; c++) {
+        for (uint32_t c = 1; c < K; c++) {  // (chunk 0 has no partner below it)
             const uint32_t lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
+            const uint32_t cnt = rcnt[c];
+            if (cnt == 0u) continue;
             for (uint32_t k0 = threadIdx.x; k0 < m; k0 += 2048u) {
-                uint32_t v[8];
+                uint32_t vd[8];
+                uint16_t vl[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
-                    v[u] = k < m ? xg[lo + k] : 0u;
+                    vd[u] = k < m ? dg[lo + k] : 0u;
+                    vl[u] = k < m ? lc[lo + k] : (uint16_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
-                    if (k < m) x[k] = v[u];
+                    if (k < m) {
+                        xd[k] = vd[u];
+                        xl[k] = vl[u];
+                    }
                 }
             }
             __syncthreads();
-            const uint32_t cnt = rcnt[c];
             const uint64_t *rl = rpool + (uint64_t)c * CB;
             for (uint32_t e0 = threadIdx.x; e0 < cnt; e0 += 2048u) {
                 uint64_t rep[8];
@@ -436,27 +509,16 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t e = e0 + 256u * (uint32_t)u;
-                    if (e < cnt) x[(uint32_t)rep[u] & (CB - 1u)] = (uint32_t)(rep[u] >> JB);
+                    if (e < cnt) {
+                        xd[(uint32_t)(rep[u] >> 48)] = (uint32_t)rep[u];
+                        xl[(uint32_t)(rep[u] >> 48)] = (uint16_t)(rep[u] >> 32);
+                    }
                 }
             }
             __syncthreads();
-            for (uint32_t k0 = threadIdx.x; k0 < m; k0 += 2048u) {
-                uint32_t loc[8], dgv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t k = k0 + 256u * (uint32_t)u;
-                    loc[u] = k < m ? x[k] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) dgv[u] = dsrc[loc[u]];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t k = k0 + 256u * (uint32_t)u, h = loc[u] >> 16;
-                    if (k < m) {
-                        xg[lo + k] = dgv[u] | ((h & 3u) << 8) | ((h >> 2) << 11);
-                        lc[lo + k] = (uint16_t)loc[u];
-                    }
-                }
+            for (uint32_t k = threadIdx.x; k < m; k += 256u) {
+                dg[lo + k] = xd[k];
+                lc[lo + k] = xl[k];
             }
             __syncthreads();
         }
