@@ -276,3 +276,46 @@ def test_philox_stream_provider_against_the_reference_with_a_replayed_stream(gpu
     for i, s in enumerate(seeds):
         assert rows[i] == [int(x) for x in d[f"s{s}_step_rows"]], s
         assert pops[i] == [int(x) for x in d[f"s{s}_step_popped"]], s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["8192", "16384"])
+def test_chunked_shuffle_of_states_that_do_not_fit_lds_equals_the_in_place_orders(chunk):
+    """offsim_shuffle_queues_keys_ws (csrc/shuffle_chunk.hpp: chunks top-down in LDS, message and reply lists) against the
+    in-place global-memory variant and, for one-state tables, against NumPy's shuffle (oracle restatement of psrs.py:29-30): segment
+    lengths around the chunk size and its multiples, several states per table, more chains than persistent workgroups take at once."""
+    import os, subprocess, sys
+    code = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import oracle as O
+from rl_offline_simulation_amd import synth, _lib as L
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+cb = int(os.environ["OFFSIM_SHUFFLE_CHUNK"])
+shapes = [(65537, 1, 3), (cb * 9 - 1, 1, 2), (cb * 9, 1, 2), (cb * 9 + 1, 1, 2), (cb * 8 + 63, 1, 2), (cb * 8 + 65, 1, 2), (300000, 2, 5), (1000000, 3, 3), (700000, 5, 700)]
+for n, nS, R in shapes:
+    e = synth.synth_iid(n, nS, 2, seed=n)
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+    pi = table.policy_slots(synth.dirichlet_policy(nS, 2))
+    seeds = [int(x) for x in np.random.default_rng(n).integers(0, 1 << 62, R)]
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
+        env = BatchedPSRS(table, R)
+        env.reset_sampler(seeds, policy=pi)
+        torch.cuda.synchronize()
+        assert (getattr(env, "_ws", None) is not None) == (mode == "1" and table.max_seg > 65536), (n, mode)
+        assert L.load().offsim_async_faults() == 0
+        out[mode] = env
+    assert torch.equal(out["1"]._dig_buf, out["0"]._dig_buf) and torch.equal(out["1"]._loc_buf, out["0"]._loc_buf), (n, nS)
+    if nS == 1:  # (as in test_gpu_fuzz.py: a one-state table's queue order is default_rng(seed).shuffle of its rows)
+        perm = (out["1"].perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+        for k, sd in enumerate(seeds):
+            assert np.array_equal(perm[k, :n], O.permutation(sd, n)), (n, sd)
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFFSIM_SHUFFLE_CHUNK=chunk)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
