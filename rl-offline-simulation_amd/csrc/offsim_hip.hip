@@ -356,11 +356,12 @@ __global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ s
 
 // Workspace of the chunked shuffle (shuffle_chunk.hpp): header (work counter, work list) + one message pool and one reply pool per
 // persistent workgroup, sized for the table's longest state.
-// Chunk size: OFFSIM_SHUFFLE_CHUNK = 8192 (default: two persistent workgroups per CU) or 16384 (one).
+// Chunk size: OFFSIM_SHUFFLE_CHUNK = 4096 (default; measured at C2 / C3: 2048: 0.077 / 1.22 s per pass, 4096: 0.071 / 1.08, 8192: 0.095 / 1.26),
+// 2048, 8192 or 16384 positions; as many persistent workgroups per CU as its LDS holds (three to five at 4096).
 #define SHC_HEADER_BYTES 4096
 static uint32_t shc_cb() {
     static const int v = getenv("OFFSIM_SHUFFLE_CHUNK") ? atoi(getenv("OFFSIM_SHUFFLE_CHUNK")) : 0;
-    return v == 16384 ? 16384u : 8192u;
+    return v == 16384 ? 16384u : v == 8192 ? 8192u : v == 2048 ? 2048u : 4096u;
 }
 static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
     const uint32_t n = (uint32_t)t->max_seg, cb = shc_cb();
@@ -391,11 +392,14 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     uint32_t msg_cap = 0;
     int64_t n_wg = 0, words = 0;
     int dev = 0, cus = 256;
+    uint32_t kcap = 0, lds_b = 0;
     if (big && workspace && ((uintptr_t)workspace & 7u) == 0) {
         words = shc_block_words(t, &msg_cap);
         n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t per_cu = shc_cb() == 8192u ? 2 : 1;  // persistent workgroups per CU (what their chunks leave of its LDS)
+        kcap = ((uint32_t)t->max_seg + shc_cb() - 1u) / shc_cb();
+        lds_b = shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u>(kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u>(kcap) : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u>(kcap) : shc_lds_bytes<8192u, 1024u, 512u>(kcap);
+        const int64_t per_cu = (160 * 1024) / (int64_t)((lds_b + 1023u) & ~1023u);  // persistent workgroups per CU (what their chunks leave of its LDS)
         n_wg = n_wg > cus * per_cu ? cus * per_cu : n_wg;
     }
     const bool chunked = n_wg >= 1;
@@ -405,15 +409,16 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
         uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
         hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, SHUF_CAP16, hdr + 64, hdr + 1, hdr);
         LAUNCH_CHECK();
-        const uint32_t role_turn = getenv("OFFSIM_SHUFFLE_TURN") ? (uint32_t)atoi(getenv("OFFSIM_SHUFFLE_TURN")) : (uint32_t)cus;
 #define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
     do {                                                                                                                                \
         HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
-        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), (shc_lds_bytes<CB, RG, SQ>()), st, t->seg_off, t->N, \
-                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, role_turn, dig32,    \
+        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), lds_b, st, t->seg_off, t->N, \
+                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, kcap, dig32,    \
                            dig_out, loc_out);                                                                                           \
     } while (0)
         if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
+        else if (shc_cb() == 4096u) SHC_LAUNCH(4096u, 1024u, 512u);
+        else if (shc_cb() == 2048u) SHC_LAUNCH(2048u, 1024u, 512u);
         else SHC_LAUNCH(8192u, 1024u, 512u);
 #undef SHC_LAUNCH
         LAUNCH_CHECK();

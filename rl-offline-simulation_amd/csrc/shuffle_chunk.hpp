@@ -52,18 +52,17 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
 }
 
-// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: KMAX + 1 w][mcnt, rcnt: KMAX w each][xd: CB + 64 w][xl: CB + 64 halfwords]
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 halfwords]
 // (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
-constexpr uint32_t shc_lds_bytes() { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * ((1u << 23) / CB) + 16u) + 6u * (CB + 64u); }
+constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * kcap + 16u) + 6u * (CB + 64u); }
 
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
 __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
-                      int64_t ws_block_words, uint32_t msg_cap, uint32_t role_turn, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
+                      int64_t ws_block_words, uint32_t msg_cap, uint32_t kcap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
                       uint16_t *__restrict__ loc_out) {
-    constexpr uint32_t KMAX = (1u << 23) / CB;
     constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
     static_assert((CB & (CB - 1u)) == 0u && JB <= 15u, "chunk size: a power of two, at most 32768 (a position inside its chunk travels in 15 bits)");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -71,16 +70,12 @@ __global__ void __launch_bounds__(256)
     lds_vu32 *ring = ctrl + 16;
     lds_vu32 *jq = ring + SHC_RG;
     lds_vu32 *win = jq + SHC_SQ + 64u;
-    lds_vu32 *moff = win + 64u, *mcnt = moff + KMAX + 16u, *rcnt = mcnt + KMAX;  // (moff[K] = the end of the last list)
+    lds_vu32 *moff = win + 64u, *mcnt = moff + kcap + 16u, *rcnt = mcnt + kcap;  // (moff[K] = the end of the last list)
     // the chunk: one RECORD per position, in the streams' own layout -- xd = the digest word (digest | bits 16.. of the local row),
     // xl = the local row's low half; entries [CB .. CB+63]: one scratch entry per lane (lanes without a partner in the chunk)
-    lds_vu32 *xd = rcnt + KMAX;
+    lds_vu32 *xd = rcnt + kcap;
     lds_vu16 *xl = (lds_vu16 *)(xd + CB + 64u);
-    // Roles by wavefront: 0 and 3 = G, 1 = C, 2 = A.  Two workgroups share a CU, and a workgroup's wavefront k runs on SIMD k: every
-    // other workgroup (the second one of each CU: workgroups are handed out CU by CU) turns its roles by two, so that the two A
-    // wavefronts -- the ones bound by what they issue -- and the two C wavefronts sit on different SIMDs.
-    const int wave_hw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wave = (wave_hw + (int)(((blockIdx.x / role_turn) & 1u) << 1)) & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // roles: 0 and 3 = G, 1 = C, 2 = A
     // this workgroup's pools: messages as {record | j inside its chunk << 48} + {i}, replies as {record | i inside its chunk << 48}
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
     uint32_t *m32 = (uint32_t *)(m64 + msg_cap);
@@ -96,7 +91,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t s = work_seg[w / (uint32_t)n_perm];
         const int32_t r = (int32_t)(w % (uint32_t)n_perm);
         const uint32_t beg = seg_off[s], n = seg_off[s + 1] - beg;
-        const uint32_t K = (n + CB - 1u) / CB;
+        const uint32_t K = (n + CB - 1u) / CB;  // (<= kcap: the launch sized the list arrays for the table's longest state)
         uint32_t *dg = dig_out + (int64_t)r * N + beg;
         uint16_t *lc = loc_out + (int64_t)r * N + beg;
         const uint32_t *dsrc = dig32 + beg;

@@ -134,20 +134,20 @@ class BatchedPSRS:
             raise ValueError(shuffle)
 
     def _shuffle_workspace(self):
-        """Workspace of the chunked shuffle (states of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for one persistent
-        two workgroups per compute unit, or for as many as 85 % of the free HBM holds (a workgroup's pools are ~21 bytes per row of the
-        longest state); None (the in-place shuffle) when the table has no
-        such state, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit."""
+        """Workspace of the chunked shuffle (states of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to four persistent
+        workgroups per compute unit, or for as many as 92 % of the free HBM holds (a workgroup's pools are ~21 bytes per row of the
+        longest state); None (the in-place shuffle) when the table has no such state, when OFFSIM_SHUFFLE_CHUNKED=0, or when not
+        even one workgroup's pools fit."""
         t = self.table
         if t.max_seg <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
             return None
         if getattr(self, "_ws", None) is None:
             lib = L.load()
-            cus = torch.cuda.get_device_properties(t.device).multi_processor_count * (1 if os.environ.get("OFFSIM_SHUFFLE_CHUNK") == "16384" else 2)
+            cus = torch.cuda.get_device_properties(t.device).multi_processor_count * 4  # (the call starts as many per CU as the LDS holds; what is lent beyond that stays unused)
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
             head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
             free = torch.cuda.mem_get_info(t.device)[0]
-            n = min(cus, max(0, (int(free * 0.85) - head) // max(one - head, 1)))
+            n = min(cus, max(0, (int(free * 0.92) - head) // max(one - head, 1)))
             if one <= 0 or n < 1:
                 return None
             self._ws = torch.empty(int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), int(n))), dtype=torch.uint8, device=t.device)
