@@ -273,9 +273,8 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG>), 160 * 1024));
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_SMALL>), 160 * 1024));
-    if ((max_seg > SHUF_CAP16 && !big_segments_elsewhere) || n0 > SHUF_CAP16) {  // first: these chains are the long ones
-        // (workgroups 0 .. n_perm-1 are the init queues: with the states' big segments served by the chunked kernel only those are launched)
-        hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)(big_segments_elsewhere ? n_perm : n_blocks)), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
+    if (!big_segments_elsewhere && (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16)) {  // first: these chains are the long ones (or the chunked kernel has them)
+        hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
                            t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
         LAUNCH_CHECK();
     }
@@ -363,14 +362,20 @@ static uint32_t shc_cb() {
     static const int v = getenv("OFFSIM_SHUFFLE_CHUNK") ? atoi(getenv("OFFSIM_SHUFFLE_CHUNK")) : 0;
     return v == 16384 ? 16384u : v == 8192 ? 8192u : v == 2048 ? 2048u : 4096u;
 }
+// rows of the longest chain the chunked kernel serves: states and the init queue, as far as they exceed the LDS capacity (0: none)
+static uint32_t shc_longest(const offsim_table *t) {
+    const int64_t a = t->max_seg > (int64_t)SHUF_CAP16 ? t->max_seg : 0, b = t->N0 > (int64_t)SHUF_CAP16 ? t->N0 : 0;
+    return (uint32_t)(a > b ? a : b);
+}
 static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
-    const uint32_t n = (uint32_t)t->max_seg, cb = shc_cb();
+    const uint32_t n = shc_longest(t), cb = shc_cb();
     const uint64_t msg = shc_pool_entries(n, cb), rep = (uint64_t)((n + cb - 1u) / cb) * cb;
     if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
-    return (int64_t)(msg + (msg + 1u) / 2u + rep);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
+    const uint64_t lcs = t->N0 > (int64_t)SHUF_CAP16 ? (uint64_t)((t->N0 + 3) / 4) : 0;  // (the init queue's unused low halves)
+    return (int64_t)(msg + (msg + 1u) / 2u + rep + lcs);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
 }
 extern "C" int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_blocks) {
-    if (!t || n_blocks < 1 || t->max_seg <= (int64_t)SHUF_CAP16 || t->max_seg > (1ll << 23) || t->n_slots > 1000) return 0;
+    if (!t || n_blocks < 1 || shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23)) return 0;
     return SHC_HEADER_BYTES + (int64_t)n_blocks * shc_block_words(t, nullptr) * 8;
 }
 
@@ -393,28 +398,30 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     int64_t n_wg = 0, words = 0;
     int dev = 0, cus = 256;
     uint32_t kcap = 0, lds_b = 0;
-    if (big && workspace && ((uintptr_t)workspace & 7u) == 0) {
+    const bool long_chains = shc_longest(t) != 0 && t->N0 <= (1ll << 23);
+    if (long_chains && workspace && ((uintptr_t)workspace & 7u) == 0) {
         words = shc_block_words(t, &msg_cap);
         n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        kcap = ((uint32_t)t->max_seg + shc_cb() - 1u) / shc_cb();
+        kcap = (shc_longest(t) + shc_cb() - 1u) / shc_cb();
         lds_b = shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u>(kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u>(kcap) : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u>(kcap) : shc_lds_bytes<8192u, 1024u, 512u>(kcap);
         const int64_t per_cu = (160 * 1024) / (int64_t)((lds_b + 1023u) & ~1023u);  // persistent workgroups per CU (what their chunks leave of its LDS)
         n_wg = n_wg > cus * per_cu ? cus * per_cu : n_wg;
     }
     const bool chunked = n_wg >= 1;
     int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
-    if (rc || !big) return rc;
+    if (rc || (!big && !chunked)) return rc;
     if (chunked) {
         uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
-        hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, SHUF_CAP16, hdr + 64, hdr + 1, hdr);
+        hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), SHUF_CAP16,
+                           hdr + 64, hdr + 1, hdr);
         LAUNCH_CHECK();
 #define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
     do {                                                                                                                                \
         HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
         hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), lds_b, st, t->seg_off, t->N, \
                            seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, kcap, dig32,    \
-                           dig_out, loc_out);                                                                                           \
+                           dig_out, loc_out, t->n_slots, t->N0, init_perm_out);                                                         \
     } while (0)
         if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
         else if (shc_cb() == 4096u) SHC_LAUNCH(4096u, 1024u, 512u);

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
                       int64_t ws_block_words, uint32_t msg_cap, uint32_t kcap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
-                      uint16_t *__restrict__ loc_out) {
+                      uint16_t *__restrict__ loc_out, int32_t n_slots, int64_t N0, uint32_t *__restrict__ init_perm) {
     constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
     static_assert((CB & (CB - 1u)) == 0u && JB <= 15u, "chunk size: a power of two, at most 32768 (a position inside its chunk travels in 15 bits)");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256)
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
     uint32_t *m32 = (uint32_t *)(m64 + msg_cap);
     uint64_t *rpool = m64 + msg_cap + (msg_cap + 1u) / 2u;
+    uint16_t *lc_init = (uint16_t *)(m64 + ws_block_words) - ((N0 + 3) & ~(int64_t)3);  // (the init queue's low halves: written, never used)
     const uint32_t n_work = n_work_seg[0] * (uint32_t)n_perm;
 
     for (;;) {
@@ -90,11 +91,13 @@ __global__ void __launch_bounds__(256)
         if (w >= n_work) return;
         const uint32_t s = work_seg[w / (uint32_t)n_perm];
         const int32_t r = (int32_t)(w % (uint32_t)n_perm);
-        const uint32_t beg = seg_off[s], n = seg_off[s + 1] - beg;
+        // (work item "state n_slots" = the rollout's init queue, psrs.py:22-23: plain row indices 0 .. N0-1, no digests)
+        const bool initq = s == (uint32_t)n_slots;
+        const uint32_t beg = initq ? 0u : seg_off[s], n = initq ? (uint32_t)N0 : seg_off[s + 1] - beg;
         const uint32_t K = (n + CB - 1u) / CB;  // (<= kcap: the launch sized the list arrays for the table's longest state)
-        uint32_t *dg = dig_out + (int64_t)r * N + beg;
-        uint16_t *lc = loc_out + (int64_t)r * N + beg;
-        const uint32_t *dsrc = dig32 + beg;
+        uint32_t *dg = initq ? init_perm + (int64_t)r * N0 : dig_out + (int64_t)r * N + beg;
+        uint16_t *lc = initq ? lc_init : loc_out + (int64_t)r * N + beg;
+        const uint32_t *dsrc = initq ? seg_off : dig32 + beg;  // (init queue: never read)
         __syncthreads();  // (everyone has read SC_WORK)
         if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0u;
         if (threadIdx.x < 64u) win[threadIdx.x] = 0u;
@@ -277,13 +280,13 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                         for (int u = 0; u < 32; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
-                            dv[u] = k < m ? dsrc[lo + k] : 0u;
+                            dv[u] = (k < m && !initq) ? dsrc[lo + k] : 0u;
                         }
 #pragma unroll
                         for (int u = 0; u < 32; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
-                                xd[k] = dv[u] | shc_hi_bits(loc);
+                                xd[k] = initq ? loc : (dv[u] | shc_hi_bits(loc));
                                 xl[k] = (uint16_t)loc;
                             }
                         }
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(256)
 #endif
             }
         } else if (threadIdx.x == 0) {  // a state with a single row
-            dg[0] = dsrc[0];
+            dg[0] = initq ? 0u : dsrc[0];
             lc[0] = 0;
         }
         __syncthreads();
@@ -523,18 +526,20 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// The states with more than `above` rows, longest first (the persistent workgroups take them in that order), and the work counter.
-__global__ void __launch_bounds__(256) k_chunk_worklist(const uint32_t *__restrict__ seg_off, int32_t n_slots, uint32_t above,
+// The chains with more than `above` rows -- states, and "state n_slots" = the init queue (N0 rows) -- longest first (the persistent
+// workgroups take them in that order), and the work counter.
+__global__ void __launch_bounds__(256) k_chunk_worklist(const uint32_t *__restrict__ seg_off, int32_t n_slots, uint32_t n0, uint32_t above,
                                                         uint32_t *__restrict__ work_seg, uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter) {
     __shared__ uint32_t cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    for (int32_t s = (int32_t)threadIdx.x; s < n_slots; s += 256) {
-        const uint32_t len = seg_off[s + 1] - seg_off[s];
+    auto len_of = [&](int32_t q) -> uint32_t { return q == n_slots ? n0 : seg_off[q + 1] - seg_off[q]; };
+    for (int32_t s = (int32_t)threadIdx.x; s <= n_slots; s += 256) {
+        const uint32_t len = len_of(s);
         if (len <= above) continue;
-        uint32_t rank = 0;  // states that come first: longer ones, and equally long ones with a smaller index
-        for (int32_t q = 0; q < n_slots; q++) {
-            const uint32_t lq = seg_off[q + 1] - seg_off[q];
+        uint32_t rank = 0;  // chains that come first: longer ones, and equally long ones with a smaller index
+        for (int32_t q = 0; q <= n_slots; q++) {
+            const uint32_t lq = len_of(q);
             rank += (lq > len || (lq == len && q < s)) ? 1u : 0u;
         }
         work_seg[rank] = (uint32_t)s;

@@ -134,12 +134,12 @@ class BatchedPSRS:
             raise ValueError(shuffle)
 
     def _shuffle_workspace(self):
-        """Workspace of the chunked shuffle (states of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to four persistent
+        """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to four persistent
         workgroups per compute unit, or for as many as 92 % of the free HBM holds (a workgroup's pools are ~21 bytes per row of the
         longest state); None (the in-place shuffle) when the table has no such state, when OFFSIM_SHUFFLE_CHUNKED=0, or when not
         even one workgroup's pools fit."""
         t = self.table
-        if t.max_seg <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
+        if max(t.max_seg, t.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
             return None
         if getattr(self, "_ws", None) is None:
             lib = L.load()

@@ -294,10 +294,12 @@ from rl_offline_simulation_amd import synth, _lib as L
 from rl_offline_simulation_amd.table import TransitionTable
 from rl_offline_simulation_amd.evaluators import BatchedPSRS
 cb = int(os.environ["OFFSIM_SHUFFLE_CHUNK"])
-shapes = [(65537, 1, 3), (cb * 9 - 1, 1, 2), (cb * 9, 1, 2), (cb * 9 + 1, 1, 2), (cb * 8 + 63, 1, 2), (cb * 8 + 65, 1, 2), (300000, 2, 5), (1000000, 3, 3), (700000, 5, 700)]
+shapes = [(65537, 1, 3), (cb * 9 - 1, 1, 2), (cb * 9, 1, 2), (cb * 9 + 1, 1, 2), (cb * 8 + 63, 1, 2), (cb * 8 + 65, 1, 2), (300000, 2, 5), (1000000, 3, 3), (700000, 5, 700), (900000, 40, 4)]
 for n, nS, R in shapes:
     e = synth.synth_iid(n, nS, 2, seed=n)
-    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+    # (every third shape: each row an initial state, so the init queue is a long chain too -- with 40 states also the ONLY long one)
+    t0 = np.ones(n, bool) if shapes.index((n, nS, R)) %% 3 == 0 else e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
     pi = table.policy_slots(synth.dirichlet_policy(nS, 2))
     seeds = [int(x) for x in np.random.default_rng(n).integers(0, 1 << 62, R)]
     out = {}
@@ -306,10 +308,11 @@ for n, nS, R in shapes:
         env = BatchedPSRS(table, R)
         env.reset_sampler(seeds, policy=pi)
         torch.cuda.synchronize()
-        assert (getattr(env, "_ws", None) is not None) == (mode == "1" and table.max_seg > 65536), (n, mode)
+        assert (getattr(env, "_ws", None) is not None) == (mode == "1" and max(table.max_seg, table.N0) > 65536), (n, mode)
         assert L.load().offsim_async_faults() == 0
         out[mode] = env
     assert torch.equal(out["1"]._dig_buf, out["0"]._dig_buf) and torch.equal(out["1"]._loc_buf, out["0"]._loc_buf), (n, nS)
+    assert torch.equal(out["1"]._init_perm_buf, out["0"]._init_perm_buf), (n, nS)
     if nS == 1:  # (as in test_gpu_fuzz.py: a one-state table's queue order is default_rng(seed).shuffle of its rows)
         perm = (out["1"].perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
         for k, sd in enumerate(seeds):
