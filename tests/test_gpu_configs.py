@@ -80,7 +80,8 @@ def test_c3_continuous_grid_learned_encoder(gpu):
     env.reset_sampler(list(range(8)), policy=table.policy_slots(pi))  # the untraced path of the bench: keyed reset + row-packed scan
     o2 = env.eval_mc(table.policy_slots(pi), 0.95)
     torch.cuda.synchronize()
-    assert env.scan_variant() == "k_eval_mc_rows"
+    import os
+    assert env.scan_variant() == "k_eval_mc_rows" or os.environ.get("OFFSIM_SCAN_ROWS", "1") == "0"  # (the variant matrix of test_gpu_edges.py)
     for k in ("steps", "cand", "n_ep", "sum_g"):
         assert torch.equal(o2[k], o[k]), k
 
