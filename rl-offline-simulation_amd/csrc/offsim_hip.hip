@@ -1521,6 +1521,27 @@ __global__ void k_selftest_lds_order(uint32_t seed0, int trials, uint32_t n_addr
         }
         if (active && got != want) nbad++;
         __syncthreads();
+        // the same for ds_wrxchg_rtn_b32 (csrc/shuffle_chunk.hpp applies a group of messages with one exchange per lane): a lane gets
+        // back what the previous lane with its address stored (or the cell's initial value), and the last lane's value stays
+        for (uint32_t i = lane; i < 256; i += 64) cell[i] = 1000u * i;
+        __syncthreads();
+        if (active) {
+            const uint32_t addr = (uint32_t)(uintptr_t)(offsim::lds_u32 *)&cell[a];
+            asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(addr), "v"(lane + 1u) : "memory");
+        }
+        want = 1000u * a;
+        uint32_t last = 1000u * a;
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t aj = __shfl(a, j);
+            const bool actj = __shfl((int)active, j);
+            if (actj && aj == a) {
+                if (j < lane) want = j + 1u;
+                last = j + 1u;
+            }
+        }
+        __syncthreads();
+        if (active && (got != want || cell[a] != last)) nbad++;
+        __syncthreads();
     }
     if (nbad) atomicAdd(bad, nbad);
 }

@@ -43,6 +43,9 @@ __host__ __device__ inline uint32_t shc_list_cap(uint32_t n, uint32_t lo, uint32
     const float mu = (float)(hi - lo) * logf((float)n / (float)hi);
     return (uint32_t)(mu + 8.0f * sqrtf(mu)) + 128u;
 }
+__device__ __forceinline__ uint32_t shc_xchg(lds_vu32 *p, uint32_t v) {
+    return __hip_atomic_exchange((__attribute__((address_space(3))) uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // bits 16.. of a local row where the digest word of stream format B carries them (bits 8, 9 and 11..15)
 __host__ __device__ inline uint32_t shc_hi_bits(uint32_t loc) { return (((loc >> 16) & 3u) << 8) | ((loc >> 18) << 11); }
 // message pool entries a workgroup needs for segments of up to n rows (host side: sizes the workspace)
@@ -52,10 +55,10 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
 }
 
-// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 halfwords]
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 w]
 // (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
-constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * kcap + 16u) + 6u * (CB + 64u); }
+constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * kcap + 16u) + 8u * (CB + 64u); }
 
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
 __global__ void __launch_bounds__(256)
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__(256)
     // the chunk: one RECORD per position, in the streams' own layout -- xd = the digest word (digest | bits 16.. of the local row),
     // xl = the local row's low half; entries [CB .. CB+63]: one scratch entry per lane (lanes without a partner in the chunk)
     lds_vu32 *xd = rcnt + kcap;
-    lds_vu16 *xl = (lds_vu16 *)(xd + CB + 64u);
+    lds_vu32 *xl = xd + CB + 64u;  // (a 32-bit word per entry: phase I exchanges it)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // roles: 0 and 3 = G, 1 = C, 2 = A
     // this workgroup's pools: messages as {record | j inside its chunk << 48} + {i}, replies as {record | i inside its chunk << 48}
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256)
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
                                 xd[k] = initq ? loc : (dv[u] | shc_hi_bits(loc));
-                                xl[k] = (uint16_t)loc;
+                                xl[k] = loc & 0xffffu;
                             }
                         }
                     }
@@ -321,24 +324,10 @@ __global__ void __launch_bounds__(256)
                                 const uint64_t msg = cur[q];
                                 const uint32_t vd = (uint32_t)msg, vl = (uint32_t)(msg >> 32) & 0xffffu, isrc = curi[q];
                                 const uint32_t adr = in ? (uint32_t)(msg >> 48) : CB + (uint32_t)lane;
-                                uint32_t od = xd[adr], ol = xl[adr];
-                                xd[adr] = (uint32_t)lane;
-                                const uint32_t tg = xd[adr];
-                                const uint64_t F = __ballot(tg != (uint32_t)lane);
-                                if (__builtin_expect(F == 0ull, 1)) {
-                                    xd[adr] = vd;
-                                    xl[adr] = (uint16_t)vl;
-                                } else {
-                                    uint32_t n_pieces;
-                                    const uint32_t pid = split(adr, od, tg, F, 0ull, sh_lowmask(cnt - g0), n_pieces);
-                                    for (uint32_t pc = 0; pc < n_pieces; pc++)
-                                        if (pid == pc) {
-                                            od = xd[adr];
-                                            ol = xl[adr];
-                                            xd[adr] = vd;
-                                            xl[adr] = (uint16_t)vl;
-                                        }
-                                }
+                                // One exchange per lane and word puts the message's record there and takes what was there.  Lanes of a group
+                                // with the same j are served in ascending lane order -- the list's order -- by the LDS itself (the property
+                                // offsim_selftest_lds_atomic_order checks): no tags, no pieces.
+                                const uint32_t od = shc_xchg(xd + adr, vd), ol = shc_xchg(xl + adr, vl);
                                 if (in) {  // what was there is the final entry of position isrc: the reply
                                     const uint32_t cs = isrc >> JB;
                                     const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(rcnt + cs), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -389,10 +378,10 @@ __global__ void __launch_bounds__(256)
                             const uint64_t F = __ballot(tg != (uint32_t)lane);
                             if (__builtin_expect((confl | F) == 0ull, 1)) {
                                 xd[adr] = ad;
-                                xl[adr] = (uint16_t)al;
+                                xl[adr] = al;
                                 if (intl) {  // (a self-swap, v == il: both pairs of stores write the same record)
                                     xd[pa] = bd;
-                                    xl[pa] = (uint16_t)bl;
+                                    xl[pa] = bl;
                                 }
                             } else {
                                 uint64_t cuts = 0, cf = confl;
@@ -409,9 +398,9 @@ __global__ void __launch_bounds__(256)
                                         if (intl) {
                                             const uint32_t b2d = xd[adr], b2l = xl[adr];
                                             xd[pa] = b2d;
-                                            xl[pa] = (uint16_t)b2l;
+                                            xl[pa] = b2l;
                                             xd[adr] = ad;
-                                            xl[adr] = (uint16_t)al;
+                                            xl[adr] = al;
                                         }
                                     }
                             }
@@ -491,7 +480,7 @@ __global__ void __launch_bounds__(256)
                     const uint32_t k = k0 + 256u * (uint32_t)u;
                     if (k < m) {
                         xd[k] = vd[u];
-                        xl[k] = vl[u];
+                        xl[k] = (uint32_t)vl[u];
                     }
                 }
             }
@@ -509,14 +498,14 @@ __global__ void __launch_bounds__(256)
                     const uint32_t e = e0 + 256u * (uint32_t)u;
                     if (e < cnt) {
                         xd[(uint32_t)(rep[u] >> 48)] = (uint32_t)rep[u];
-                        xl[(uint32_t)(rep[u] >> 48)] = (uint16_t)(rep[u] >> 32);
+                        xl[(uint32_t)(rep[u] >> 48)] = (uint32_t)(rep[u] >> 32) & 0xffffu;
                     }
                 }
             }
             __syncthreads();
             for (uint32_t k = threadIdx.x; k < m; k += 256u) {
                 dg[lo + k] = xd[k];
-                lc[lo + k] = xl[k];
+                lc[lo + k] = (uint16_t)xl[k];
             }
             __syncthreads();
         }
