@@ -55,10 +55,10 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     return tot + tot / 64u + 1024u;  // (slack for float rounding between host and device and between segment sizes)
 }
 
-// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][win 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 w]
+// LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 w]
 // (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
-constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 64u + 3u * kcap + 16u) + 8u * (CB + 64u); }
+constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 3u * kcap + 16u) + 8u * (CB + 64u); }
 
 template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
 __global__ void __launch_bounds__(256)
@@ -72,8 +72,7 @@ __global__ void __launch_bounds__(256)
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
     lds_vu32 *jq = ring + SHC_RG;
-    lds_vu32 *win = jq + SHC_SQ + 64u;
-    lds_vu32 *moff = win + 64u, *mcnt = moff + kcap + 16u, *rcnt = mcnt + kcap;  // (moff[K] = the end of the last list)
+    lds_vu32 *moff = jq + SHC_SQ + 64u, *mcnt = moff + kcap + 16u, *rcnt = mcnt + kcap;  // (moff[K] = the end of the last list)
     // the chunk: one RECORD per position, in the streams' own layout -- xd = the digest word (digest | bits 16.. of the local row),
     // xl = the local row's low half; entries [CB .. CB+63]: one scratch entry per lane (lanes without a partner in the chunk)
     lds_vu32 *xd = rcnt + kcap;
@@ -103,7 +102,6 @@ __global__ void __launch_bounds__(256)
         const uint32_t *dsrc = initq ? seg_off : dig32 + beg;  // (init queue: never read)
         __syncthreads();  // (everyone has read SC_WORK)
         if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0u;
-        if (threadIdx.x < 64u) win[threadIdx.x] = 0u;
         for (uint32_t k = threadIdx.x; k < K; k += 256u) {
             const uint32_t lo = k * CB, hi = lo + CB < n ? lo + CB : n;
             moff[k + 1u] = shc_list_cap(n, lo, hi);
@@ -259,22 +257,6 @@ __global__ void __launch_bounds__(256)
 #else
 #define SHC_PH(x)
 #endif
-                // duplicates among the 64 addresses of a group (adr: this lane's entry of the chunk, or its scratch entry): the lanes that
-                // share an entry with an earlier lane start a new piece; returns the piece number of every lane and the number of pieces
-                auto split = [&](uint32_t adr, uint32_t b, uint32_t tg, uint64_t F, uint64_t cuts, uint64_t valid, uint32_t &n_pieces) -> uint32_t {
-                    xd[adr] = b;  // take the tags back
-                    if (F) {
-                        const bool lost = tg != (uint32_t)lane;
-                        if (lost) win[tg] = 1u;
-                        const uint32_t wv = win[(uint32_t)lane];
-                        if (lost) win[tg] = 0u;
-                        const uint64_t D = F | __ballot(wv != 0u);
-                        cuts |= D & (D - 1ull);
-                    }
-                    cuts &= valid & ~1ull;  // (a cut in front of lane 0 separates nothing)
-                    n_pieces = (uint32_t)__popcll(cuts) + 1u;
-                    return (uint32_t)sh_rank(cuts) + (uint32_t)((cuts >> lane) & 1ull);
-                };
                 for (int32_t cc = (int32_t)K - 1; cc >= 0; cc--) {
                     const uint32_t c = (uint32_t)cc, lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
                     // identity: position lo + k holds the record of local row lo + k (its digest comes in sequentially: 4 B per row)
@@ -369,17 +351,15 @@ __global__ void __launch_bounds__(256)
                         const uint32_t pa = in ? il - lo : CB + (uint32_t)lane;
                         uint32_t ad = xd[pa], al = xl[pa];
                         if (__ballot(intl) != 0ull) {  // (a group whose partners all lie below the chunk only sends)
-                            // a partner that is the position of a LATER step of the group: that step has to see this swap
+                            // Swaps inside the chunk: the record at il goes to the partner's entry by an exchange, what was there comes back to
+                            // il.  Lanes with the SAME partner need nothing more (the LDS serves them in lane order = step order: each gets what
+                            // the one before it put there).  Only a partner that is the position of a LATER step of the group splits the
+                            // group: that step has to read its entry after this swap.
                             const uint64_t confl = __ballot(intl && v < il && v > i_low);
                             const uint32_t adr = intl ? v - lo : CB + (uint32_t)lane;
-                            const uint32_t bd = xd[adr], bl = xl[adr];
-                            xd[adr] = (uint32_t)lane;  // tag: lanes with the same partner see one winner
-                            const uint32_t tg = xd[adr];
-                            const uint64_t F = __ballot(tg != (uint32_t)lane);
-                            if (__builtin_expect((confl | F) == 0ull, 1)) {
-                                xd[adr] = ad;
-                                xl[adr] = al;
-                                if (intl) {  // (a self-swap, v == il: both pairs of stores write the same record)
+                            if (__builtin_expect(confl == 0ull, 1)) {
+                                const uint32_t bd = shc_xchg(xd + adr, ad), bl = shc_xchg(xl + adr, al);
+                                if (intl) {  // (a self-swap, v == il, gets its own record back)
                                     xd[pa] = bd;
                                     xl[pa] = bl;
                                 }
@@ -389,18 +369,17 @@ __global__ void __launch_bounds__(256)
                                     cuts |= 1ull << (i_top - sh_rfl((uint32_t)__builtin_amdgcn_readlane((int)v, (int)sh_ff1(cf))));
                                     cf &= cf - 1ull;
                                 }
-                                uint32_t n_pieces;
-                                const uint32_t pid = split(adr, bd, tg, F, cuts, sh_lowmask(cnt), n_pieces);
+                                cuts &= sh_lowmask(cnt) & ~1ull;
+                                const uint32_t n_pieces = (uint32_t)__popcll(cuts) + 1u;
+                                const uint32_t pid = (uint32_t)sh_rank(cuts) + (uint32_t)((cuts >> lane) & 1ull);
                                 for (uint32_t pc = 0; pc < n_pieces; pc++)
                                     if (pid == pc && in) {
                                         ad = xd[pa];
                                         al = xl[pa];
                                         if (intl) {
-                                            const uint32_t b2d = xd[adr], b2l = xl[adr];
-                                            xd[pa] = b2d;
-                                            xl[pa] = b2l;
-                                            xd[adr] = ad;
-                                            xl[adr] = al;
+                                            const uint32_t bd = shc_xchg(xd + adr, ad), bl = shc_xchg(xl + adr, al);
+                                            xd[pa] = bd;
+                                            xl[pa] = bl;
                                         }
                                     }
                             }
