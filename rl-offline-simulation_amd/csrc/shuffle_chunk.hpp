@@ -43,6 +43,23 @@ __host__ __device__ inline uint32_t shc_list_cap(uint32_t n, uint32_t lo, uint32
     const float mu = (float)(hi - lo) * logf((float)n / (float)hi);
     return (uint32_t)(mu + 8.0f * sqrtf(mu)) + 128u;
 }
+// read a dword per lane into LDS at lds_dst_uniform + 4 * lane without a register for the data (brings the line into L2)
+__device__ __forceinline__ void shc_touch(const void *gptr, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_dst_uniform)
+        : "memory");
+}
+// the next slot of a list (lanes of one instruction that take from the same counter get ascending slots in lane order)
+__device__ __forceinline__ uint32_t shc_take(lds_vu32 *p) {
+    return __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ uint32_t shc_xchg(lds_vu32 *p, uint32_t v) {
     return __hip_atomic_exchange((__attribute__((address_space(3))) uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -260,15 +277,15 @@ __global__ void __launch_bounds__(256)
                 for (int32_t cc = (int32_t)K - 1; cc >= 0; cc--) {
                     const uint32_t c = (uint32_t)cc, lo = c * CB, hi = lo + CB < n ? lo + CB : n, m = hi - lo;
                     // identity: position lo + k holds the record of local row lo + k (its digest comes in sequentially: 4 B per row)
-                    for (uint32_t k0 = (uint32_t)lane; k0 < m; k0 += 2048u) {
-                        uint32_t dv[32];
+                    for (uint32_t k0 = (uint32_t)lane; k0 < m; k0 += 1024u) {
+                        uint32_t dv[16];
 #pragma unroll
-                        for (int u = 0; u < 32; u++) {
+                        for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
                             dv[u] = (k < m && !initq) ? dsrc[lo + k] : 0u;
                         }
 #pragma unroll
-                        for (int u = 0; u < 32; u++) {
+                        for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
                                 xd[k] = initq ? loc : (dv[u] | shc_hi_bits(loc));
@@ -309,12 +326,12 @@ __global__ void __launch_bounds__(256)
                                 // One exchange per lane and word puts the message's record there and takes what was there.  Lanes of a group
                                 // with the same j are served in ascending lane order -- the list's order -- by the LDS itself (the property
                                 // offsim_selftest_lds_atomic_order checks): no tags, no pieces.
+                                // (the slot of the reply in its list is taken in the same LDS round trip)
+                                const uint32_t cs = isrc >> JB;
                                 const uint32_t od = shc_xchg(xd + adr, vd), ol = shc_xchg(xl + adr, vl);
-                                if (in) {  // what was there is the final entry of position isrc: the reply
-                                    const uint32_t cs = isrc >> JB;
-                                    const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(rcnt + cs), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const uint32_t slot = shc_take(in ? rcnt + cs : ctrl + 15);
+                                if (in)  // what was there is the final entry of position isrc: the reply
                                     rpool[(uint64_t)cs * CB + slot] = (uint64_t)od | ((uint64_t)ol << 32) | ((uint64_t)(isrc & (CB - 1u)) << 48);
-                                }
                             }
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
@@ -349,7 +366,12 @@ __global__ void __launch_bounds__(256)
                         const bool intl = in && v >= lo, ext = in && v < lo;
                         const uint32_t i_low = i_top - cnt;  // the group's steps are i_top .. i_low + 1
                         const uint32_t pa = in ? il - lo : CB + (uint32_t)lane;
+                        // (one LDS round trip: the record at il, and for a partner in a lower chunk the slot of the message in that chunk's list --
+                        // in step order: ascending lanes -- and the list's bounds)
+                        const uint32_t d = ext ? v >> JB : 0u;
                         uint32_t ad = xd[pa], al = xl[pa];
+                        const uint32_t mo = moff[d], me = moff[d + 1u];
+                        const uint32_t slot = shc_take(ext ? mcnt + d : ctrl + 15);
                         if (__ballot(intl) != 0ull) {  // (a group whose partners all lie below the chunk only sends)
                             // Swaps inside the chunk: the record at il goes to the partner's entry by an exchange, what was there comes back to
                             // il.  Lanes with the SAME partner need nothing more (the LDS serves them in lane order = step order: each gets what
@@ -384,11 +406,8 @@ __global__ void __launch_bounds__(256)
                                     }
                             }
                         }
-                        if (ext) {  // the partner lies in a lower chunk: (i, j, the record at i) goes to that chunk's list, in step order
-                            const uint32_t d = v >> JB;
-                            const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(mcnt + d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const uint32_t mo = moff[d];
-                            if (slot < moff[d + 1u] - mo) {
+                        if (ext) {  // the partner lies in a lower chunk: (i, j, the record at i) goes to that chunk's list
+                            if (slot < me - mo) {
                                 m64[mo + slot] = (uint64_t)ad | ((uint64_t)al << 32) | ((uint64_t)(v & (CB - 1u)) << 48);
                                 m32[mo + slot] = il;
                             } else {
@@ -396,6 +415,12 @@ __global__ void __launch_bounds__(256)
                             }
                         }
                         i_top -= cnt;  // (never below lo - 1, and chunk 0 ends at step 1: no wrap)
+                        if (!initq && c > 0u && i_top - lo == CB / 4u - 1u) {  // a quarter of the chunk to go: bring the next chunk's digests into L2
+                            // (one load per 64-byte sector, as LDS-DMA into the lanes' scratch entries: no register waits for the data)
+                            const uint32_t sc_a = sh_rfl((uint32_t)(uintptr_t)(xd + CB));
+#pragma unroll
+                            for (uint32_t u = 0; u < CB / 1024u; u++) shc_touch(dsrc + (lo - CB) + ((uint32_t)lane + 64u * u) * 16u, sc_a);
+                        }
                     }
                     SHC_PH(pf_ii);
                     if (__builtin_expect(sh_ld(ctrl + SH_ABORT) == 2u, 0)) {  // a list overflowed
