@@ -39,6 +39,9 @@ enum { SC_WORK = 11, SC_NCH = 12 };  // further words of the control block (SH_*
 
 // messages a chunk list of a segment of n rows has to hold (see above); host and device use the same expression
 __host__ __device__ inline uint32_t shc_list_cap(uint32_t n, uint32_t lo, uint32_t hi) {
+#ifdef SHC_TEST_SMALL_LISTS  // (test build: lists that overflow, so that the fault path runs)
+    return 16u;
+#endif
     if (hi >= n) return 128u;
     const float mu = (float)(hi - lo) * logf((float)n / (float)hi);
     return (uint32_t)(mu + 8.0f * sqrtf(mu)) + 128u;

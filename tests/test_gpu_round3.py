@@ -160,7 +160,7 @@ def test_shuffle_protocol_slip_ends_with_an_error_not_a_hang(gpu):
     here = os.path.dirname(os.path.abspath(__file__))
     lib = os.path.join(os.path.dirname(here), "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
     if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT"],
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
                               env=dict(os.environ, OUT="variants/lib_fault.so"))
     code = """
 import sys, time
@@ -322,3 +322,51 @@ print("ok")
     env = dict(os.environ, OFFSIM_SHUFFLE_CHUNK=chunk)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_chunked_shuffle_list_overflow_raises_the_fault_and_a_small_workspace_falls_back(gpu):
+    """csrc/shuffle_chunk.hpp: (1) a message list that overflows (-DSHC_TEST_SMALL_LISTS in variants/lib_fault.so: 16 entries per
+    list) ends the chain with OFFSIM_FAULT_SHUFFLE instead of writing past its list, and the call returns; (2) a workspace that does
+    not hold one workgroup's pools gives the in-place shuffle -- same orders."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
+                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    code = """
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch
+from rl_offline_simulation_amd import synth, _lib as L
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+n = 200000
+e = synth.synth_iid(n, 1, 2, seed=1)
+t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], np.ones(n, bool))  # both chains are long
+env = BatchedPSRS(t, 4)
+assert L.load().offsim_async_faults() == 0
+t0 = time.time()
+env.reset_sampler([1, 2, 3, 4], policy=t.policy_slots(synth.dirichlet_policy(1, 2)))
+torch.cuda.synchronize()
+dt = time.time() - t0
+v = L.load().offsim_async_faults()
+print("FAULTS", v, "SECONDS", round(dt, 2))
+assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
+""" % os.path.dirname(here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OFFSIM_LIB=lib), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # (2), in this process with the product library
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(150000, 1, 2, seed=2)
+    t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi = t.policy_slots(synth.dirichlet_policy(1, 2))
+    a, b = BatchedPSRS(t, 3), BatchedPSRS(t, 3)
+    b._ws = torch.empty(8192, dtype=torch.uint8, device=gpu)  # header + 4 KB: no pools
+    a.reset_sampler([7, 8, 9], policy=pi)
+    b.reset_sampler([7, 8, 9], policy=pi)
+    torch.cuda.synchronize()
+    assert a._ws.numel() > (1 << 20) and L.load().offsim_async_faults() == 0
+    assert torch.equal(a._dig_buf, b._dig_buf) and torch.equal(a._loc_buf, b._loc_buf) and torch.equal(a._init_perm_buf, b._init_perm_buf)
