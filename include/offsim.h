@@ -346,6 +346,9 @@ int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int
  * holds none (or NULL) gives offsim_shuffle_queues_keys.  Orders are the same bit for bit.  A message list of the chunked kernel
  * that overflowed (probability ~1e-15 per list) raises OFFSIM_FAULT_SHUFFLE (offsim_async_faults): the call's orders are void. */
 int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_workgroups);
+/* offsim_shuffle_queues with such a workspace: the same permutations, the chains of more than 65536 rows chunk by chunk on chip. */
+int offsim_shuffle_queues_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
+                             void *workspace, int64_t workspace_bytes, void *stream);
 int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
                                   uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
                                   void *stream);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "offsim_shuffle_queues_keys": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "offsim_shuffle_queues_keys_ws": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "offsim_shuffle_workspace_bytes": (_i64, [C.POINTER(Table), _i32]),
+    "offsim_shuffle_queues_ws": (C.c_int, [C.POINTER(Table), _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "offsim_eval_mc_streams": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), C.POINTER(Streams), _vp, C.c_double, _vp, _i64, _i64,
                                          C.POINTER(EvalMCOut), _vp]),
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,

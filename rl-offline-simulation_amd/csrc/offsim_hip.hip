@@ -367,16 +367,70 @@ static uint32_t shc_longest(const offsim_table *t) {
     const int64_t a = t->max_seg > (int64_t)SHUF_CAP16 ? t->max_seg : 0, b = t->N0 > (int64_t)SHUF_CAP16 ? t->N0 : 0;
     return (uint32_t)(a > b ? a : b);
 }
-static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out) {
+static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out, int64_t *lc_words_out = nullptr) {
     const uint32_t n = shc_longest(t), cb = shc_cb();
     const uint64_t msg = shc_pool_entries(n, cb), rep = (uint64_t)((n + cb - 1u) / cb) * cb;
     if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
-    const uint64_t lcs = t->N0 > (int64_t)SHUF_CAP16 ? (uint64_t)((t->N0 + 3) / 4) : 0;  // (the init queue's unused low halves)
-    return (int64_t)(msg + (msg + 1u) / 2u + rep + lcs);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
+    if (lc_words_out) *lc_words_out = (int64_t)((n + 3u) / 4u);  // (16-bit scratch for the low halves of plain records)
+    return (int64_t)(msg + (msg + 1u) / 2u + rep + (n + 3u) / 4u);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
 }
 extern "C" int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_blocks) {
     if (!t || n_blocks < 1 || shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23)) return 0;
     return SHC_HEADER_BYTES + (int64_t)n_blocks * shc_block_words(t, nullptr) * 8;
+}
+
+// The chunked kernel for the chains that do not fit LDS, if the caller lent a workspace that holds at least one workgroup's pools:
+// *n_wg_out = the persistent workgroups it will run with (0: not applicable -- the in-place form has to serve those chains).
+// perm_out != NULL: the orders go out as permutations (plain records); otherwise as the streams dig_out / loc_out.
+struct ShcPlan {
+    int64_t n_wg = 0, words = 0, lc_words = 0;
+    uint32_t msg_cap = 0, kcap = 0, lds_b = 0;
+};
+static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspace_bytes) {
+    ShcPlan p;
+    if (shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23) || !workspace || ((uintptr_t)workspace & 7u) != 0) return p;
+    p.words = shc_block_words(t, &p.msg_cap, &p.lc_words);
+    p.n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (p.words * 8);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    p.kcap = (shc_longest(t) + shc_cb() - 1u) / shc_cb();
+    p.lds_b = shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u>(p.kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u>(p.kcap)
+            : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u>(p.kcap) : shc_lds_bytes<8192u, 1024u, 512u>(p.kcap);
+    const int64_t per_cu = (160 * 1024) / (int64_t)((p.lds_b + 1023u) & ~1023u);  // persistent workgroups per CU (what their chunks leave of its LDS)
+    p.n_wg = p.n_wg > cus * per_cu ? cus * per_cu : p.n_wg;
+    if (p.n_wg < 1) p.n_wg = 0;
+    return p;
+}
+static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, uint32_t *dig_out,
+                      uint16_t *loc_out, uint32_t *init_perm_out, uint32_t *perm_out, void *workspace, hipStream_t st) {
+    uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of long chains, [64 ..] their indices, longest first
+    hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), SHUF_CAP16,
+                       hdr + 64, hdr + 1, hdr);
+    LAUNCH_CHECK();
+#define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
+    do {                                                                                                                                \
+        HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
+        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)p.n_wg), dim3(256), p.lds_b, st, t->seg_off, t->N, seeds, n_perm,  \
+                           hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), p.words, p.msg_cap, p.kcap, dig32,   \
+                           dig_out, loc_out, t->n_slots, t->N0, init_perm_out, perm_out, p.lc_words);                                   \
+    } while (0)
+    if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
+    else if (shc_cb() == 4096u) SHC_LAUNCH(4096u, 1024u, 512u);
+    else if (shc_cb() == 2048u) SHC_LAUNCH(2048u, 1024u, 512u);
+    else SHC_LAUNCH(8192u, 1024u, 512u);
+#undef SHC_LAUNCH
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_shuffle_queues_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
+                                        void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");
+    if (n_perm == 0) return OFFSIM_OK;
+    const ShcPlan p = t->max_seg > 0 ? shc_plan(t, workspace, workspace_bytes) : ShcPlan();  // (max_seg unknown: the in-place form)
+    int rc = launch_shuffle(t, seeds, n_perm, perm_out, init_perm_out, nullptr, nullptr, nullptr, (hipStream_t)stream, p.n_wg >= 1);
+    if (rc || p.n_wg < 1) return rc;
+    return shc_launch(p, t, seeds, n_perm, nullptr, nullptr, nullptr, init_perm_out, perm_out, workspace, (hipStream_t)stream);
 }
 
 extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
@@ -392,45 +446,13 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     if (big && (t->max_seg > (1ll << 23) || t->n_slots > 256)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 256 states%s");
     if (n_perm == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
-    // the states that do not fit LDS: the chunked kernel when the caller lent a workspace that holds at least one workgroup's pools,
-    // otherwise in place in global memory (the state's slice of dig_out) and one more pass that turns the order into streams
-    uint32_t msg_cap = 0;
-    int64_t n_wg = 0, words = 0;
-    int dev = 0, cus = 256;
-    uint32_t kcap = 0, lds_b = 0;
-    const bool long_chains = shc_longest(t) != 0 && t->N0 <= (1ll << 23);
-    if (long_chains && workspace && ((uintptr_t)workspace & 7u) == 0) {
-        words = shc_block_words(t, &msg_cap);
-        n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (words * 8);
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        kcap = (shc_longest(t) + shc_cb() - 1u) / shc_cb();
-        lds_b = shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u>(kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u>(kcap) : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u>(kcap) : shc_lds_bytes<8192u, 1024u, 512u>(kcap);
-        const int64_t per_cu = (160 * 1024) / (int64_t)((lds_b + 1023u) & ~1023u);  // persistent workgroups per CU (what their chunks leave of its LDS)
-        n_wg = n_wg > cus * per_cu ? cus * per_cu : n_wg;
-    }
-    const bool chunked = n_wg >= 1;
+    // the chains that do not fit LDS: the chunked kernel when the caller lent a workspace that holds at least one workgroup's pools,
+    // otherwise in place in global memory (a state: in its slice of dig_out) and one more pass that turns the order into streams
+    const ShcPlan p = shc_plan(t, workspace, workspace_bytes);
+    const bool chunked = p.n_wg >= 1;
     int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
     if (rc || (!big && !chunked)) return rc;
-    if (chunked) {
-        uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of big states, [64 ..] their indices, longest first
-        hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), SHUF_CAP16,
-                           hdr + 64, hdr + 1, hdr);
-        LAUNCH_CHECK();
-#define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
-    do {                                                                                                                                \
-        HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
-        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)n_wg), dim3(256), lds_b, st, t->seg_off, t->N, \
-                           seeds, n_perm, hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), words, msg_cap, kcap, dig32,    \
-                           dig_out, loc_out, t->n_slots, t->N0, init_perm_out);                                                         \
-    } while (0)
-        if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
-        else if (shc_cb() == 4096u) SHC_LAUNCH(4096u, 1024u, 512u);
-        else if (shc_cb() == 2048u) SHC_LAUNCH(2048u, 1024u, 512u);
-        else SHC_LAUNCH(8192u, 1024u, 512u);
-#undef SHC_LAUNCH
-        LAUNCH_CHECK();
-        return OFFSIM_OK;
-    }
+    if (chunked) return shc_launch(p, t, seeds, n_perm, dig32, dig_out, loc_out, init_perm_out, nullptr, workspace, st);
     if (n_perm > 65535) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: more than 65535 orders of a big-segment table per call%s");
     hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)n_perm), dim3(256), 0, st,
                        t->seg_off, t->N, dig32, dig_out, loc_out);

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
                       int64_t ws_block_words, uint32_t msg_cap, uint32_t kcap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
-                      uint16_t *__restrict__ loc_out, int32_t n_slots, int64_t N0, uint32_t *__restrict__ init_perm) {
+                      uint16_t *__restrict__ loc_out, int32_t n_slots, int64_t N0, uint32_t *__restrict__ init_perm, uint32_t *__restrict__ perm_out,
+                      int64_t lc_words) {
     constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
     static_assert((CB & (CB - 1u)) == 0u && JB <= 15u, "chunk size: a power of two, at most 32768 (a position inside its chunk travels in 15 bits)");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -102,7 +103,9 @@ __global__ void __launch_bounds__(256)
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
     uint32_t *m32 = (uint32_t *)(m64 + msg_cap);
     uint64_t *rpool = m64 + msg_cap + (msg_cap + 1u) / 2u;
-    uint16_t *lc_init = (uint16_t *)(m64 + ws_block_words) - ((N0 + 3) & ~(int64_t)3);  // (the init queue's low halves: written, never used)
+    // (chains whose records are plain row indices -- the init queue, and every chain when the orders go out as permutations, perm_out != NULL --
+    // have no use for the records' low halves: those are written to this scratch area)
+    uint16_t *lc_plain = (uint16_t *)(m64 + ws_block_words - lc_words);
     const uint32_t n_work = n_work_seg[0] * (uint32_t)n_perm;
 
     for (;;) {
@@ -114,12 +117,13 @@ __global__ void __launch_bounds__(256)
         const uint32_t s = work_seg[w / (uint32_t)n_perm];
         const int32_t r = (int32_t)(w % (uint32_t)n_perm);
         // (work item "state n_slots" = the rollout's init queue, psrs.py:22-23: plain row indices 0 .. N0-1, no digests)
-        const bool initq = s == (uint32_t)n_slots;
+        const bool initq = s == (uint32_t)n_slots, plain = initq || perm_out != nullptr;
         const uint32_t beg = initq ? 0u : seg_off[s], n = initq ? (uint32_t)N0 : seg_off[s + 1] - beg;
         const uint32_t K = (n + CB - 1u) / CB;  // (<= kcap: the launch sized the list arrays for the table's longest state)
-        uint32_t *dg = initq ? init_perm + (int64_t)r * N0 : dig_out + (int64_t)r * N + beg;
-        uint16_t *lc = initq ? lc_init : loc_out + (int64_t)r * N + beg;
-        const uint32_t *dsrc = initq ? seg_off : dig32 + beg;  // (init queue: never read)
+        uint32_t *dg = initq ? init_perm + (int64_t)r * N0 : (perm_out ? perm_out : dig_out) + (int64_t)r * N + beg;
+        uint16_t *lc = plain ? lc_plain : loc_out + (int64_t)r * N + beg;
+        const uint32_t base_val = initq ? 0u : beg;  // (a plain record = the grouped row, or the index into the init rows)
+        const uint32_t *dsrc = plain ? seg_off : dig32 + beg;  // (plain records: never read)
         __syncthreads();  // (everyone has read SC_WORK)
         if (threadIdx.x < 16u) ctrl[threadIdx.x] = 0u;
         for (uint32_t k = threadIdx.x; k < K; k += 256u) {
@@ -285,13 +289,13 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
                         for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
-                            dv[u] = (k < m && !initq) ? dsrc[lo + k] : 0u;
+                            dv[u] = (k < m && !plain) ? dsrc[lo + k] : 0u;
                         }
 #pragma unroll
                         for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
-                                xd[k] = initq ? loc : (dv[u] | shc_hi_bits(loc));
+                                xd[k] = plain ? base_val + loc : (dv[u] | shc_hi_bits(loc));
                                 xl[k] = loc & 0xffffu;
                             }
                         }
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__(256)
                             }
                         }
                         i_top -= cnt;  // (never below lo - 1, and chunk 0 ends at step 1: no wrap)
-                        if (!initq && c > 0u && i_top - lo == CB / 4u - 1u) {  // a quarter of the chunk to go: bring the next chunk's digests into L2
+                        if (!plain && c > 0u && i_top - lo == CB / 4u - 1u) {  // a quarter of the chunk to go: bring the next chunk's digests into L2
                             // (one load per 64-byte sector, as LDS-DMA into the lanes' scratch entries: no register waits for the data)
                             const uint32_t sc_a = sh_rfl((uint32_t)(uintptr_t)(xd + CB));
 #pragma unroll
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(256)
 #endif
             }
         } else if (threadIdx.x == 0) {  // a state with a single row
-            dg[0] = initq ? 0u : dsrc[0];
+            dg[0] = plain ? base_val : dsrc[0];
             lc[0] = 0;
         }
         __syncthreads();

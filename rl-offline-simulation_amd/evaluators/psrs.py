@@ -113,11 +113,11 @@ class BatchedPSRS:
                 self._dig_buf = self._loc_buf = None
                 if self._perm_buf is None or self._perm_buf.shape[0] != self.R:
                     self._perm_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
-                shuffle_queues(t, sd, self._perm_buf, self._init_perm_buf)
+                shuffle_queues(t, sd, self._perm_buf, self._init_perm_buf, workspace=self._shuffle_workspace())
                 self.state.set_orders(self._perm_buf, t.N, self._init_perm_buf, t.N0)
         elif shuffle == SHUFFLE_SHARED:
             assert shuffle_seed is not None
-            perm, init_perm = shuffle_queues(t, seeds_tensor([shuffle_seed], dev))
+            perm, init_perm = shuffle_queues(t, seeds_tensor([shuffle_seed], dev), workspace=self._shuffle_workspace(1))
             self._perm_buf, self._init_perm_buf = perm, init_perm
             self.state.set_orders(perm, 0, init_perm, 0)
             if keyed:  # one shared order: the streams are one row, built from the permutation
@@ -133,24 +133,30 @@ class BatchedPSRS:
         else:
             raise ValueError(shuffle)
 
-    def _shuffle_workspace(self):
-        """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to four persistent
-        workgroups per compute unit, or for as many as 92 % of the free HBM holds (a workgroup's pools are ~21 bytes per row of the
-        longest state); None (the in-place shuffle) when the table has no such state, when OFFSIM_SHUFFLE_CHUNKED=0, or when not
-        even one workgroup's pools fit."""
+    def _shuffle_workspace(self, n_orders=None):
+        """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to
+        four persistent workgroups per compute unit -- no more than there are chains (`n_orders` queue orders x (states + 1)) -- or for
+        as many as 92 % of the free HBM holds (a workgroup's pools are ~22 bytes per row of the longest chain); None (the in-place
+        shuffle) when the table has no such chain, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit."""
         t = self.table
         if max(t.max_seg, t.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
             return None
-        if getattr(self, "_ws", None) is None:
-            lib = L.load()
-            cus = torch.cuda.get_device_properties(t.device).multi_processor_count * 4  # (the call starts as many per CU as the LDS holds; what is lent beyond that stays unused)
+        lib = L.load()
+        want = torch.cuda.get_device_properties(t.device).multi_processor_count * 4
+        want = min(want, max(1, (self.R if n_orders is None else n_orders) * (t.n_slots + 1)))
+        have = getattr(self, "_ws", None)
+        if have is None or getattr(self, "_ws_wg", 0) < want:
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
             head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
-            free = torch.cuda.mem_get_info(t.device)[0]
-            n = min(cus, max(0, (int(free * 0.92) - head) // max(one - head, 1)))
-            if one <= 0 or n < 1:
+            if one <= 0:
                 return None
+            self._ws = None
+            free = torch.cuda.mem_get_info(t.device)[0]
+            n = min(want, max(0, (int(free * 0.92) - head) // max(one - head, 1)))
+            if n < 1:
+                return have
             self._ws = torch.empty(int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), int(n))), dtype=torch.uint8, device=t.device)
+            self._ws_wg = want  # (what was asked for: a smaller grant is not asked for again)
         return self._ws
 
     # ---- candidate streams for the row-packed scan ----

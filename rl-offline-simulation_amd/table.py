@@ -220,13 +220,15 @@ def seed_streams(seeds_dev, out=None):
     return out
 
 
-def shuffle_queues(table, seeds_dev, perm=None, init_perm=None):
-    """PSRS.reset_sampler's shuffles for every seed (psrs.py:22-23,29-30): perm [n,N], init_perm [n,N0] (uint32)."""
+def shuffle_queues(table, seeds_dev, perm=None, init_perm=None, workspace=None):
+    """PSRS.reset_sampler's shuffles for every seed (psrs.py:22-23,29-30): perm [n,N], init_perm [n,N0] (uint32).  `workspace` (a
+    uint8 device tensor of offsim_shuffle_workspace_bytes): chains of more than 65536 rows run on the chunked kernel."""
     n = seeds_dev.numel()
     dev = table.device
     if perm is None:
         perm = torch.empty((n, max(table.N, 1)), dtype=torch.int32, device=dev)
     if init_perm is None:
         init_perm = torch.empty((n, max(table.N0, 1)), dtype=torch.int32, device=dev)
-    L.check(L.load().offsim_shuffle_queues(C.byref(table.c), L.ptr(seeds_dev), n, L.ptr(perm), L.ptr(init_perm), L.stream_ptr()))
+    L.check(L.load().offsim_shuffle_queues_ws(C.byref(table.c), L.ptr(seeds_dev), n, L.ptr(perm), L.ptr(init_perm), L.ptr(workspace),
+                                              0 if workspace is None else workspace.numel(), L.stream_ptr()))
     return perm, init_perm

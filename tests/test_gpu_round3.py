@@ -313,6 +313,16 @@ for n, nS, R in shapes:
         out[mode] = env
     assert torch.equal(out["1"]._dig_buf, out["0"]._dig_buf) and torch.equal(out["1"]._loc_buf, out["0"]._loc_buf), (n, nS)
     assert torch.equal(out["1"]._init_perm_buf, out["0"]._init_perm_buf), (n, nS)
+    plain = {}
+    for mode in ("1", "0"):  # the same chains as permutations (offsim_shuffle_queues_ws)
+        os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
+        env = BatchedPSRS(table, R)
+        env.reset_sampler(seeds)
+        torch.cuda.synchronize()
+        assert L.load().offsim_async_faults() == 0
+        plain[mode] = env
+    assert torch.equal(plain["1"].state.perm, plain["0"].state.perm) and torch.equal(plain["1"].state.init_perm, plain["0"].state.init_perm), (n, nS)
+    assert torch.equal(plain["1"].state.perm.to(torch.int64) & 0xFFFFFFFF, out["1"].perm.to(torch.int64) & 0xFFFFFFFF), (n, nS)
     if nS == 1:  # (as in test_gpu_fuzz.py: a one-state table's queue order is default_rng(seed).shuffle of its rows)
         perm = (out["1"].perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
         for k, sd in enumerate(seeds):
