@@ -135,7 +135,8 @@ class BatchedPSRS:
 
     def _shuffle_workspace(self, n_orders=None):
         """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to
-        four persistent workgroups per compute unit -- no more than there are chains (`n_orders` queue orders x (states + 1)) -- or for
+        four persistent workgroups per compute unit -- no more than there are chains (`n_orders` queue orders x (states + 1)), nor than
+        keeps each busy with about four of the longest -- or for
         as many as 92 % of the free HBM holds (a workgroup's pools are ~22 bytes per row of the longest chain); None (the in-place
         shuffle) when the table has no such chain, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit."""
         t = self.table
@@ -143,7 +144,11 @@ class BatchedPSRS:
             return None
         lib = L.load()
         want = torch.cuda.get_device_properties(t.device).multi_processor_count * 4
-        want = min(want, max(1, (self.R if n_orders is None else n_orders) * (t.n_slots + 1)))
+        n_orders = self.R if n_orders is None else n_orders
+        want = min(want, max(1, n_orders * (t.n_slots + 1)))
+        # (no more workgroups than keeps each busy with about four chains of the longest kind: a small job does not wait for gigabytes
+        # of pools to be allocated)
+        want = min(want, max(8, n_orders * getattr(t, "long_rows", t.N) // (4 * max(t.max_seg, t.N0, 1))))
         have = getattr(self, "_ws", None)
         if have is None or getattr(self, "_ws_wg", 0) < want:
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))

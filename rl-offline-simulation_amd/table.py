@@ -126,6 +126,8 @@ class TransitionTable:
         lens = so[1:] - so[:-1]
         self.max_seg = int(lens.max().item()) if N else 0
         self.min_seg = int(lens[lens > 0].min().item()) if N else 0
+        # rows of the chains that do not fit the shuffle's LDS (states and the init queue): sizes the chunked shuffle's workspace
+        self.long_rows = (int(lens[lens > 65536].sum().item()) if N else 0) + (self.N0 if self.N0 > 65536 else 0)
         self.c = L.Table(N=N, n_slots=self.n_slots, nA=self.nA, plog_dtype=_TAG_OF[self.p_log.dtype],
                          r_dtype=_TAG_OF[self.r.dtype], seg_off=L.ptr(self.seg_off), p_log=L.ptr(self.p_log),
                          a=L.ptr(self.a), r=L.ptr(self.r), z_next=L.ptr(self.z_next), done=L.ptr(self.done),
