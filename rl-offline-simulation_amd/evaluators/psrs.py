@@ -171,8 +171,15 @@ class BatchedPSRS:
         t = self.table
         p = policy if isinstance(policy, torch.Tensor) else np.asarray(policy)
         f64 = p.dtype in (torch.float64, np.float64, np.dtype(np.float64))
+        # Which scan: the row-packed kernel tops a state's 8-entry window up once per tick of 16 steps, the window kernel (one rollout
+        # per wavefront, csrc/scan_win.hpp) refills on the spot.  A state that is visited more often than its window can be topped up
+        # runs dry step after step, and every dry step is an exact-path iteration of the whole wavefront: measured (DESIGN 4.2,
+        # 10 M rows, equal states) the row-packed kernel wins at 50 states (2 % of the rows each: 1.23 against 1.42 s) and loses at 25
+        # (4 %: 1.62 against 1.41 s; 12 states: 2.54 against 1.43 s).  OFFSIM_SCAN_ROWS = 1 / 0 forces the one or the other.
+        mode = os.environ.get("OFFSIM_SCAN_ROWS", "auto")
+        hot = t.max_seg * 33 > t.N  # some state holds more than 3 % of the rows
         return (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
-                and os.environ.get("OFFSIM_SCAN_ROWS", "1") != "0")
+                and mode != "0" and (mode == "1" or not hot))
 
     def _stream_format(self):
         """Layout of the digest stream (include/offsim.h): A while every state has at most 65536 rows (21-bit thresholds, 16-bit local

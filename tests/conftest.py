@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The product picks the scan kernel by the table (BatchedPSRS._streams_apply: a table with a hot state takes the window kernel).  The
+    # small tables of this suite nearly all have one, so the suite FORCES the row-packed kernel wherever it applies -- it is the headline
+    # kernel -- and runs the window kernel through the variant matrix (test_gpu_edges.py) and the tests that switch to it; the automatic
+    # choice has its own test (test_gpu_round3.py).
+    os.environ.setdefault("OFFSIM_SCAN_ROWS", "1")
 
 
 @pytest.fixture(scope="session")

@@ -129,5 +129,6 @@ def test_randomised_queue_lengths_shuffle_equals_numpy_generator_shuffle():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("OFFSIM_SCAN_ROWS", "1")  # (as tests/conftest.py: the sweep is about the row-packed kernel)
     b, _, _ = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 600, int(sys.argv[2]) if len(sys.argv) > 2 else 0, big=len(sys.argv) > 3)
     sys.exit(1 if b else 0)

@@ -363,11 +363,12 @@ def test_keyed_reset_sampler_streams_equal_the_permutations(N, nS, skew, gpu):
     # and the two forms evaluate identically (row-packed scan on streams vs the window kernels on permutations)
     cap = N + 1
     o1 = keyed.eval_mc(pi, 0.97, ep_cap=table.N0 + 1, trace_cap=cap)
+    prev = os.environ.get("OFFSIM_SCAN_ROWS", "1")
     os.environ["OFFSIM_SCAN_ROWS"] = "0"
     try:
         o0 = plain.eval_mc(pi, 0.97, ep_cap=table.N0 + 1, trace_cap=cap)
     finally:
-        del os.environ["OFFSIM_SCAN_ROWS"]
+        os.environ["OFFSIM_SCAN_ROWS"] = prev
     assert plain._streams is None
     torch.cuda.synchronize()
     for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status", "trace_row", "trace_pop", "ep_g", "ep_len"):
@@ -396,11 +397,12 @@ def test_row_packed_scan_matches_the_window_kernel_at_scale(gpu):
         assert a.scan_variant() == "k_eval_mc_rows"
         b = BatchedPSRS(table, R)
         b.reset_sampler(seeds, mode, shuffle_seed=99)
+        prev = os.environ.get("OFFSIM_SCAN_ROWS", "1")
         os.environ["OFFSIM_SCAN_ROWS"] = "0"
         try:
             ob = b.eval_mc(pi, 0.99)
         finally:
-            del os.environ["OFFSIM_SCAN_ROWS"]
+            os.environ["OFFSIM_SCAN_ROWS"] = prev
         torch.cuda.synchronize()
         for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status"):
             assert torch.equal(oa[k], ob[k]), (R, mode, k)
@@ -553,11 +555,12 @@ def test_headline_job_every_rollout_two_independent_kernels(gpu):
             o = env.eval_mc(pi, 0.99)
         else:
             env.reset_sampler(seeds)
+            prev = os.environ.get("OFFSIM_SCAN_ROWS", "1")
             os.environ["OFFSIM_SCAN_ROWS"] = "0"
             try:
                 o = env.eval_mc(pi, 0.99)
             finally:
-                del os.environ["OFFSIM_SCAN_ROWS"]
+                os.environ["OFFSIM_SCAN_ROWS"] = prev
         torch.cuda.synchronize()
         res.append({k: o[k].clone() for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status")} |
                    {"cursor": env.state.cursor.clone(), "rng": env.state.rng.clone(), "cur_slot": env.state.cur_slot.clone()})

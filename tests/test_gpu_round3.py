@@ -380,3 +380,42 @@ assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
     torch.cuda.synchronize()
     assert a._ws.numel() > (1 << 20) and L.load().offsim_async_faults() == 0
     assert torch.equal(a._dig_buf, b._dig_buf) and torch.equal(a._loc_buf, b._loc_buf) and torch.equal(a._init_perm_buf, b._init_perm_buf)
+
+
+def test_scan_kernel_is_chosen_by_the_table(gpu):
+    """BatchedPSRS._streams_apply without OFFSIM_SCAN_ROWS: a table whose largest state holds more than 3 % of the rows takes the window
+    kernel on permutations, one without such a state the row-packed kernel on streams; both give the oracle's results (child process:
+    the suite itself forces the row-packed kernel, tests/conftest.py)."""
+    import os, subprocess, sys
+    code = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import oracle as O
+from rl_offline_simulation_amd import synth
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+assert "OFFSIM_SCAN_ROWS" not in os.environ
+for nS, want in ((10, "k_eval_mc_win"), (120, "k_eval_mc_rows")):
+    e = synth.synth_iid(60000, nS, 3, seed=nS)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    pi = synth.dirichlet_policy(nS, 3)
+    seeds = [3, 4, 5, 6, 7]
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds, policy=table.policy_slots(pi))
+    o = env.eval_mc(table.policy_slots(pi), 0.98, ep_cap=table.N0 + 1)
+    torch.cuda.synchronize()
+    assert env.scan_variant() == want, (nS, env.scan_variant(), table.max_seg, table.N)
+    ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    for i, sd in enumerate(seeds):
+        ora.reset_sampler(sd)
+        ref = ora.evalmc(10 ** 9, pi, 0.98)
+        ne = int(o["n_ep"][i])
+        assert int(o["steps"][i]) == ref["steps"] and int(o["cand"][i]) == ref["candidates"] and ne == len(ref["Gs"])
+        assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+print("ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "OFFSIM_SCAN_ROWS"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
