@@ -386,7 +386,7 @@ struct ShcPlan {
     int64_t n_wg = 0, words = 0, lc_words = 0;
     uint32_t msg_cap = 0, kcap = 0, lds_b = 0;
 };
-static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspace_bytes) {
+static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspace_bytes, bool plain) {
     ShcPlan p;
     if (shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23) || !workspace || ((uintptr_t)workspace & 7u) != 0) return p;
     p.words = shc_block_words(t, &p.msg_cap, &p.lc_words);
@@ -394,8 +394,11 @@ static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspac
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     p.kcap = (shc_longest(t) + shc_cb() - 1u) / shc_cb();
-    p.lds_b = shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u>(p.kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u>(p.kcap)
-            : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u>(p.kcap) : shc_lds_bytes<8192u, 1024u, 512u>(p.kcap);
+#define SHC_LDSB(PL)                                                                                                                    \
+    (shc_cb() == 16384u ? shc_lds_bytes<16384u, 2048u, 1024u, PL>(p.kcap) : shc_cb() == 4096u ? shc_lds_bytes<4096u, 1024u, 512u, PL>(p.kcap) \
+     : shc_cb() == 2048u ? shc_lds_bytes<2048u, 1024u, 512u, PL>(p.kcap) : shc_lds_bytes<8192u, 1024u, 512u, PL>(p.kcap))
+    p.lds_b = plain ? SHC_LDSB(true) : SHC_LDSB(false);
+#undef SHC_LDSB
     const int64_t per_cu = (160 * 1024) / (int64_t)((p.lds_b + 1023u) & ~1023u);  // persistent workgroups per CU (what their chunks leave of its LDS)
     p.n_wg = p.n_wg > cus * per_cu ? cus * per_cu : p.n_wg;
     if (p.n_wg < 1) p.n_wg = 0;
@@ -407,18 +410,24 @@ static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *s
     hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), SHUF_CAP16,
                        hdr + 64, hdr + 1, hdr);
     LAUNCH_CHECK();
-#define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
+#define SHC_LAUNCH_(CB, RG, SQ, PL)                                                                                                     \
     do {                                                                                                                                \
-        HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ>), 160 * 1024));                                                             \
-        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ>), dim3((unsigned)p.n_wg), dim3(256), p.lds_b, st, t->seg_off, t->N, seeds, n_perm,  \
+        HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ, PL>), 160 * 1024));                                                         \
+        hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ, PL>), dim3((unsigned)p.n_wg), dim3(256), p.lds_b, st, t->seg_off, t->N, seeds, n_perm,  \
                            hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), p.words, p.msg_cap, p.kcap, dig32,   \
                            dig_out, loc_out, t->n_slots, t->N0, init_perm_out, perm_out, p.lc_words);                                   \
+    } while (0)
+#define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
+    do {                                                                                                                                \
+        if (perm_out) SHC_LAUNCH_(CB, RG, SQ, true);                                                                                    \
+        else SHC_LAUNCH_(CB, RG, SQ, false);                                                                                            \
     } while (0)
     if (shc_cb() == 16384u) SHC_LAUNCH(16384u, 2048u, 1024u);
     else if (shc_cb() == 4096u) SHC_LAUNCH(4096u, 1024u, 512u);
     else if (shc_cb() == 2048u) SHC_LAUNCH(2048u, 1024u, 512u);
     else SHC_LAUNCH(8192u, 1024u, 512u);
 #undef SHC_LAUNCH
+#undef SHC_LAUNCH_
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }
@@ -427,7 +436,7 @@ extern "C" int offsim_shuffle_queues_ws(const offsim_table *t, const uint64_t *s
                                         void *workspace, int64_t workspace_bytes, void *stream) {
     if (!t || !seeds || n_perm < 0 || !perm_out || !init_perm_out) return fail(OFFSIM_EINVAL, "shuffle_queues: bad argument%s");
     if (n_perm == 0) return OFFSIM_OK;
-    const ShcPlan p = t->max_seg > 0 ? shc_plan(t, workspace, workspace_bytes) : ShcPlan();  // (max_seg unknown: the in-place form)
+    const ShcPlan p = t->max_seg > 0 ? shc_plan(t, workspace, workspace_bytes, true) : ShcPlan();  // (max_seg unknown: the in-place form)
     int rc = launch_shuffle(t, seeds, n_perm, perm_out, init_perm_out, nullptr, nullptr, nullptr, (hipStream_t)stream, p.n_wg >= 1);
     if (rc || p.n_wg < 1) return rc;
     return shc_launch(p, t, seeds, n_perm, nullptr, nullptr, nullptr, init_perm_out, perm_out, workspace, (hipStream_t)stream);
@@ -448,7 +457,7 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     hipStream_t st = (hipStream_t)stream;
     // the chains that do not fit LDS: the chunked kernel when the caller lent a workspace that holds at least one workgroup's pools,
     // otherwise in place in global memory (a state: in its slice of dig_out) and one more pass that turns the order into streams
-    const ShcPlan p = shc_plan(t, workspace, workspace_bytes);
+    const ShcPlan p = shc_plan(t, workspace, workspace_bytes, false);
     const bool chunked = p.n_wg >= 1;
     int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
     if (rc || (!big && !chunked)) return rc;

@@ -77,10 +77,11 @@ inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
 
 // LDS: [ctrl 16 w][draw ring RG w][j ring SQ + 64 w][moff: kcap + 1 w][mcnt, rcnt: kcap w each] (kcap = chunks of the table's longest state)[xd: CB + 64 w][xl: CB + 64 w]
 // (RG raw draws in the ring, SQ partners in the j ring: powers of two, RG a multiple of 256, SQ >= 384)
-template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
-constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 3u * kcap + 16u) + 8u * (CB + 64u); }
+// (PLAIN: every chain's records are plain row indices -- the orders go out as permutations -- and the second word of an entry does not exist)
+template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ, bool PLAIN>
+constexpr uint32_t shc_lds_bytes(uint32_t kcap) { return 4u * (16u + SHC_RG + SHC_SQ + 64u + 3u * kcap + 16u) + (PLAIN ? 4u : 8u) * (CB + 64u); }
 
-template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ>
+template <uint32_t CB, uint32_t SHC_RG, uint32_t SHC_SQ, bool PLAIN>
 __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256)
     // the chunk: one RECORD per position, in the streams' own layout -- xd = the digest word (digest | bits 16.. of the local row),
     // xl = the local row's low half; entries [CB .. CB+63]: one scratch entry per lane (lanes without a partner in the chunk)
     lds_vu32 *xd = rcnt + kcap;
-    lds_vu32 *xl = xd + CB + 64u;  // (a 32-bit word per entry: phase I exchanges it)
+    lds_vu32 *xl = xd + (PLAIN ? 0u : CB + 64u);  // (a 32-bit word per entry: phase I exchanges it; PLAIN: not there, never touched)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // roles: 0 and 3 = G, 1 = C, 2 = A
     // this workgroup's pools: messages as {record | j inside its chunk << 48} + {i}, replies as {record | i inside its chunk << 48}
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
@@ -296,7 +297,7 @@ __global__ void __launch_bounds__(256)
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
                                 xd[k] = plain ? base_val + loc : (dv[u] | shc_hi_bits(loc));
-                                xl[k] = loc & 0xffffu;
+                                if (!PLAIN) xl[k] = loc & 0xffffu;
                             }
                         }
                     }
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256)
                                 // offsim_selftest_lds_atomic_order checks): no tags, no pieces.
                                 // (the slot of the reply in its list is taken in the same LDS round trip)
                                 const uint32_t cs = isrc >> JB;
-                                const uint32_t od = shc_xchg(xd + adr, vd), ol = shc_xchg(xl + adr, vl);
+                                const uint32_t od = shc_xchg(xd + adr, vd), ol = PLAIN ? 0u : shc_xchg(xl + adr, vl);
                                 const uint32_t slot = shc_take(in ? rcnt + cs : ctrl + 15);
                                 if (in)  // what was there is the final entry of position isrc: the reply
                                     rpool[(uint64_t)cs * CB + slot] = (uint64_t)od | ((uint64_t)ol << 32) | ((uint64_t)(isrc & (CB - 1u)) << 48);
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256)
                         // (one LDS round trip: the record at il, and for a partner in a lower chunk the slot of the message in that chunk's list --
                         // in step order: ascending lanes -- and the list's bounds)
                         const uint32_t d = ext ? v >> JB : 0u;
-                        uint32_t ad = xd[pa], al = xl[pa];
+                        uint32_t ad = xd[pa], al = PLAIN ? 0u : xl[pa];
                         const uint32_t mo = moff[d], me = moff[d + 1u];
                         const uint32_t slot = shc_take(ext ? mcnt + d : ctrl + 15);
                         if (__ballot(intl) != 0ull) {  // (a group whose partners all lie below the chunk only sends)
@@ -387,10 +388,10 @@ __global__ void __launch_bounds__(256)
                             const uint64_t confl = __ballot(intl && v < il && v > i_low);
                             const uint32_t adr = intl ? v - lo : CB + (uint32_t)lane;
                             if (__builtin_expect(confl == 0ull, 1)) {
-                                const uint32_t bd = shc_xchg(xd + adr, ad), bl = shc_xchg(xl + adr, al);
+                                const uint32_t bd = shc_xchg(xd + adr, ad), bl = PLAIN ? 0u : shc_xchg(xl + adr, al);
                                 if (intl) {  // (a self-swap, v == il, gets its own record back)
                                     xd[pa] = bd;
-                                    xl[pa] = bl;
+                                    if (!PLAIN) xl[pa] = bl;
                                 }
                             } else {
                                 uint64_t cuts = 0, cf = confl;
@@ -404,11 +405,11 @@ __global__ void __launch_bounds__(256)
                                 for (uint32_t pc = 0; pc < n_pieces; pc++)
                                     if (pid == pc && in) {
                                         ad = xd[pa];
-                                        al = xl[pa];
+                                        if (!PLAIN) al = xl[pa];
                                         if (intl) {
-                                            const uint32_t bd = shc_xchg(xd + adr, ad), bl = shc_xchg(xl + adr, al);
+                                            const uint32_t bd = shc_xchg(xd + adr, ad), bl = PLAIN ? 0u : shc_xchg(xl + adr, al);
                                             xd[pa] = bd;
-                                            xl[pa] = bl;
+                                            if (!PLAIN) xl[pa] = bl;
                                         }
                                     }
                             }
@@ -442,14 +443,14 @@ __global__ void __launch_bounds__(256)
                         for (int u = 0; u < 8; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
                             vd[u] = xd[k < m ? k : 0u];
-                            vl[u] = xl[k < m ? k : 0u];
+                            vl[u] = PLAIN ? 0u : xl[k < m ? k : 0u];
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
                             if (k < m) {
                                 dg[lo + k] = vd[u];
-                                lc[lo + k] = (uint16_t)vl[u];
+                                if (!PLAIN) lc[lo + k] = (uint16_t)vl[u];
                             }
                         }
                     }
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(256)
             }
         } else if (threadIdx.x == 0) {  // a state with a single row
             dg[0] = plain ? base_val : dsrc[0];
-            lc[0] = 0;
+            if (!PLAIN) lc[0] = 0;
         }
         __syncthreads();
 #ifdef SHC_PROF
@@ -484,14 +485,14 @@ __global__ void __launch_bounds__(256)
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
                     vd[u] = k < m ? dg[lo + k] : 0u;
-                    vl[u] = k < m ? lc[lo + k] : (uint16_t)0;
+                    vl[u] = (k < m && !PLAIN) ? lc[lo + k] : (uint16_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
                     if (k < m) {
                         xd[k] = vd[u];
-                        xl[k] = (uint32_t)vl[u];
+                        if (!PLAIN) xl[k] = (uint32_t)vl[u];
                     }
                 }
             }
@@ -509,14 +510,14 @@ __global__ void __launch_bounds__(256)
                     const uint32_t e = e0 + 256u * (uint32_t)u;
                     if (e < cnt) {
                         xd[(uint32_t)(rep[u] >> 48)] = (uint32_t)rep[u];
-                        xl[(uint32_t)(rep[u] >> 48)] = (uint32_t)(rep[u] >> 32) & 0xffffu;
+                        if (!PLAIN) xl[(uint32_t)(rep[u] >> 48)] = (uint32_t)(rep[u] >> 32) & 0xffffu;
                     }
                 }
             }
             __syncthreads();
             for (uint32_t k = threadIdx.x; k < m; k += 256u) {
                 dg[lo + k] = xd[k];
-                lc[lo + k] = (uint16_t)xl[k];
+                if (!PLAIN) lc[lo + k] = (uint16_t)xl[k];
             }
             __syncthreads();
         }
