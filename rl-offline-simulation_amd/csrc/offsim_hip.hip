@@ -367,11 +367,12 @@ static uint32_t shc_longest(const offsim_table *t) {
     const int64_t a = t->max_seg > (int64_t)SHUF_CAP16 ? t->max_seg : 0, b = t->N0 > (int64_t)SHUF_CAP16 ? t->N0 : 0;
     return (uint32_t)(a > b ? a : b);
 }
-static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out, int64_t *lc_words_out = nullptr) {
+static int64_t shc_block_words(const offsim_table *t, uint32_t *msg_cap_out, int64_t *lc_words_out = nullptr, bool plain = false) {
     const uint32_t n = shc_longest(t), cb = shc_cb();
     const uint64_t msg = shc_pool_entries(n, cb), rep = (uint64_t)((n + cb - 1u) / cb) * cb;
     if (msg_cap_out) *msg_cap_out = (uint32_t)msg;
-    if (lc_words_out) *lc_words_out = (int64_t)((n + 3u) / 4u);  // (16-bit scratch for the low halves of plain records)
+    if (lc_words_out) *lc_words_out = plain ? 0 : (int64_t)((n + 3u) / 4u);  // (16-bit scratch for the low halves of an init queue's plain records)
+    if (plain) return (int64_t)(msg + rep);  // (orders as permutations: a message is one 64-bit word, and so is a reply)
     return (int64_t)(msg + (msg + 1u) / 2u + rep + (n + 3u) / 4u);  // messages: a 64-bit and a 32-bit word each; replies: one 64-bit word
 }
 extern "C" int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_blocks) {
@@ -389,7 +390,7 @@ struct ShcPlan {
 static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspace_bytes, bool plain) {
     ShcPlan p;
     if (shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23) || !workspace || ((uintptr_t)workspace & 7u) != 0) return p;
-    p.words = shc_block_words(t, &p.msg_cap, &p.lc_words);
+    p.words = shc_block_words(t, &p.msg_cap, &p.lc_words, plain);
     p.n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (p.words * 8);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

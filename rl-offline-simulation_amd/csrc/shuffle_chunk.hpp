@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256)
     // this workgroup's pools: messages as {record | j inside its chunk << 48} + {i}, replies as {record | i inside its chunk << 48}
     uint64_t *m64 = ws + (int64_t)blockIdx.x * ws_block_words;
     uint32_t *m32 = (uint32_t *)(m64 + msg_cap);
-    uint64_t *rpool = m64 + msg_cap + (msg_cap + 1u) / 2u;
+    uint64_t *rpool = m64 + msg_cap + (PLAIN ? 0u : (msg_cap + 1u) / 2u);  // (PLAIN: a message is one word: row 23 bits | j << 23 | i << (23 + JB))
     // (chains whose records are plain row indices -- the init queue, and every chain when the orders go out as permutations, perm_out != NULL --
     // have no use for the records' low halves: those are written to this scratch area)
     uint16_t *lc_plain = (uint16_t *)(m64 + ws_block_words - lc_words);
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256)
                         for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
-                                xd[k] = plain ? base_val + loc : (dv[u] | shc_hi_bits(loc));
+                                xd[k] = PLAIN ? loc : plain ? base_val + loc : (dv[u] | shc_hi_bits(loc));  // (PLAIN: the base goes on at the stores)
                                 if (!PLAIN) xl[k] = loc & 0xffffu;
                             }
                         }
@@ -314,14 +314,14 @@ __global__ void __launch_bounds__(256)
                         for (int q = 0; q < 8; q++) {
                             const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
                             cur[q] = e < cnt ? ml[e] : 0ull;
-                            curi[q] = e < cnt ? mi[e] : 0u;
+                            curi[q] = (e < cnt && !PLAIN) ? mi[e] : 0u;
                         }
                         for (uint32_t b0 = 0; b0 < cnt; b0 += 512u) {
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
                                 const uint32_t e = b0 + 512u + (uint32_t)q * 64u + (uint32_t)lane;
                                 nxt[q] = e < cnt ? ml[e] : 0ull;
-                                nxti[q] = e < cnt ? mi[e] : 0u;
+                                nxti[q] = (e < cnt && !PLAIN) ? mi[e] : 0u;
                             }
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
@@ -329,8 +329,9 @@ __global__ void __launch_bounds__(256)
                                 if (g0 >= cnt) break;
                                 const bool in = g0 + (uint32_t)lane < cnt;
                                 const uint64_t msg = cur[q];
-                                const uint32_t vd = (uint32_t)msg, vl = (uint32_t)(msg >> 32) & 0xffffu, isrc = curi[q];
-                                const uint32_t adr = in ? (uint32_t)(msg >> 48) : CB + (uint32_t)lane;
+                                const uint32_t vd = PLAIN ? (uint32_t)msg & 0x7fffffu : (uint32_t)msg, vl = (uint32_t)(msg >> 32) & 0xffffu;
+                                const uint32_t isrc = PLAIN ? (uint32_t)(msg >> (23u + JB)) : curi[q];
+                                const uint32_t adr = !in ? CB + (uint32_t)lane : PLAIN ? (uint32_t)(msg >> 23) & (CB - 1u) : (uint32_t)(msg >> 48);
                                 // One exchange per lane and word puts the message's record there and takes what was there.  Lanes of a group
                                 // with the same j are served in ascending lane order -- the list's order -- by the LDS itself (the property
                                 // offsim_selftest_lds_atomic_order checks): no tags, no pieces.
@@ -416,8 +417,12 @@ __global__ void __launch_bounds__(256)
                         }
                         if (ext) {  // the partner lies in a lower chunk: (i, j, the record at i) goes to that chunk's list
                             if (slot < me - mo) {
-                                m64[mo + slot] = (uint64_t)ad | ((uint64_t)al << 32) | ((uint64_t)(v & (CB - 1u)) << 48);
-                                m32[mo + slot] = il;
+                                if (PLAIN) {
+                                    m64[mo + slot] = (uint64_t)ad | ((uint64_t)(v & (CB - 1u)) << 23) | ((uint64_t)il << (23u + JB));
+                                } else {
+                                    m64[mo + slot] = (uint64_t)ad | ((uint64_t)al << 32) | ((uint64_t)(v & (CB - 1u)) << 48);
+                                    m32[mo + slot] = il;
+                                }
                             } else {
                                 ctrl[SH_ABORT] = 2u;
                             }
@@ -449,7 +454,7 @@ __global__ void __launch_bounds__(256)
                         for (int u = 0; u < 8; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u;
                             if (k < m) {
-                                dg[lo + k] = vd[u];
+                                dg[lo + k] = PLAIN ? base_val + vd[u] : vd[u];
                                 if (!PLAIN) lc[lo + k] = (uint16_t)vl[u];
                             }
                         }
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(256)
 #endif
             }
         } else if (threadIdx.x == 0) {  // a state with a single row
-            dg[0] = plain ? base_val : dsrc[0];
+            dg[0] = plain ? base_val : dsrc[0];  // (a single row)
             if (!PLAIN) lc[0] = 0;
         }
         __syncthreads();
@@ -509,7 +514,7 @@ __global__ void __launch_bounds__(256)
                 for (int u = 0; u < 8; u++) {
                     const uint32_t e = e0 + 256u * (uint32_t)u;
                     if (e < cnt) {
-                        xd[(uint32_t)(rep[u] >> 48)] = (uint32_t)rep[u];
+                        xd[(uint32_t)(rep[u] >> 48)] = PLAIN ? base_val + (uint32_t)rep[u] : (uint32_t)rep[u];
                         if (!PLAIN) xl[(uint32_t)(rep[u] >> 48)] = (uint32_t)(rep[u] >> 32) & 0xffffu;
                     }
                 }

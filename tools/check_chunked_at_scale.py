@@ -14,15 +14,18 @@ for wl, N in (("grid", 10_000_000), ("cartpole", 10_000_000)):
     pi = table.policy_slots(synth.dirichlet_policy(a.n_states, a.n_actions))
     R = 48
     seeds = [int(x) for x in np.random.default_rng(3).integers(0, 1 << 62, R)]
-    out = {}
-    for mode in ("1", "0"):
-        os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
-        env = BatchedPSRS(table, R)
-        torch.cuda.synchronize(); t1 = time.time()
-        env.reset_sampler(seeds, policy=pi)
-        torch.cuda.synchronize(); dt = time.time() - t1
-        out[mode] = (env._dig_buf, env._loc_buf, env._init_perm_buf, dt, L.load().offsim_async_faults())
-    same = all(torch.equal(out["1"][k], out["0"][k]) for k in range(3))
-    print(wl, "max_seg", table.max_seg, "N0", table.N0, "equal", same, "faults", out["1"][4], out["0"][4], "t %.3f / %.3f" % (out["1"][3], out["0"][3]), flush=True)
-    del out, env
-    torch.cuda.empty_cache()
+    for form in ("streams", "permutations"):  # (both forms of the orders: OFFSIM_SCAN_ROWS forces the one or the other)
+        os.environ["OFFSIM_SCAN_ROWS"] = "1" if form == "streams" else "0"
+        out = {}
+        for mode in ("1", "0"):
+            os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
+            env = BatchedPSRS(table, R)
+            torch.cuda.synchronize(); t1 = time.time()
+            env.reset_sampler(seeds, policy=pi)
+            torch.cuda.synchronize(); dt = time.time() - t1
+            bufs = (env._dig_buf, env._loc_buf, env._init_perm_buf) if form == "streams" else (env.state.perm, env._init_perm_buf)
+            out[mode] = (bufs, dt, L.load().offsim_async_faults())
+        same = all(torch.equal(x, y) for x, y in zip(out["1"][0], out["0"][0]))
+        print(wl, form, "max_seg", table.max_seg, "N0", table.N0, "equal", same, "faults", out["1"][2], out["0"][2], "t %.3f / %.3f" % (out["1"][1], out["0"][1]), flush=True)
+        del out, env
+        torch.cuda.empty_cache()
