@@ -279,7 +279,7 @@ def test_philox_stream_provider_against_the_reference_with_a_replayed_stream(gpu
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", ["8192", "16384"])
+@pytest.mark.parametrize("chunk", ["4096", "8192", "16384"])
 def test_chunked_shuffle_of_states_that_do_not_fit_lds_equals_the_in_place_orders(chunk):
     """offsim_shuffle_queues_keys_ws (csrc/shuffle_chunk.hpp: chunks top-down in LDS, message and reply lists) against the
     in-place global-memory variant and, for one-state tables, against NumPy's shuffle (oracle restatement of psrs.py:29-30): segment
