@@ -166,20 +166,38 @@ class BatchedPSRS:
 
     # ---- candidate streams for the row-packed scan ----
     def _streams_apply(self, policy):
-        """The streams exist for what offsim_eval_mc_streams covers: f64 probabilities, the default reject rule, <= 256 states,
-        segments <= 65536 rows (16-bit local rows)."""
+        """Whether the candidate streams and the row-packed scan serve `policy` on this table: what offsim_eval_mc_streams covers (f64
+        probabilities, the default reject rule, <= 256 states, states of up to 2^23 rows), and -- unless OFFSIM_SCAN_ROWS forces it --
+        where that kernel is the faster one (below)."""
         t = self.table
         p = policy if isinstance(policy, torch.Tensor) else np.asarray(policy)
         f64 = p.dtype in (torch.float64, np.float64, np.dtype(np.float64))
         # Which scan: the row-packed kernel tops a state's 8-entry window up once per tick of 16 steps, the window kernel (one rollout
-        # per wavefront, csrc/scan_win.hpp) refills on the spot.  A state that is visited more often than its window can be topped up
-        # runs dry step after step, and every dry step is an exact-path iteration of the whole wavefront: measured (DESIGN 4.2,
-        # 10 M rows, equal states) the row-packed kernel wins at 50 states (2 % of the rows each: 1.23 against 1.42 s) and loses at 25
-        # (4 %: 1.62 against 1.41 s; 12 states: 2.54 against 1.43 s).  OFFSIM_SCAN_ROWS = 1 / 0 forces the one or the other.
+        # per wavefront, csrc/scan_win.hpp) refills on the spot.  A window that runs dry makes an exact-path iteration of the whole
+        # wavefront, and it runs dry when its state is visited more often than it can be topped up (a hot state) or when a look
+        # rejects all eight entries (probability (1 - acceptance)^8).  Measured (DESIGN 4.2; 10 M rows, equal states, scan seconds per
+        # pass, row-packed / window kernel): 162 states at acceptance 0.54: 1.01 / 1.75, 0.38: 1.20 / 1.17, 0.29: 1.46 / 1.18, 0.24:
+        # 1.61 / 1.18; acceptance 0.54 with 50 states (2 % of the rows each): 1.23 / 1.42, 35: 1.39 / 1.41, 25: 1.62 / 1.41, 12: 2.54 / 1.43.
+        # So: the row-packed kernel when no state holds more than 3 % of the rows AND the policy's acceptance is at least 0.4.
+        # OFFSIM_SCAN_ROWS = 1 / 0 forces the one or the other.
         mode = os.environ.get("OFFSIM_SCAN_ROWS", "auto")
-        hot = t.max_seg * 33 > t.N  # some state holds more than 3 % of the rows
-        return (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
-                and mode != "0" and (mode == "1" or not hot))
+        ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
+              and mode != "0")
+        if not ok or mode == "1":
+            return ok
+        if t.max_seg * 33 > t.N:  # some state holds more than 3 % of the rows
+            return False
+        return self._acceptance(policy) >= 0.4
+
+    def _acceptance(self, policy):
+        """Acceptance probability of a candidate under `policy`, averaged over the table's rows: the mean of the compiled thresholds'
+        top 21 bits (one reduction and one host read per policy; cached with the compiled keys)."""
+        key = self._policy_key(policy)
+        if getattr(self, "_acc_cache", None) is None or self._acc_cache[0] != key:
+            keys, _ = self._policy_keys(policy, key=key)
+            a = float((((keys >> 43) & 0x1FFFFF).to(torch.float64)).mean().item()) / 2 ** 21 if self.table.N else 1.0
+            self._acc_cache = (key, a)
+        return self._acc_cache[1]
 
     def _stream_format(self):
         """Layout of the digest stream (include/offsim.h): A while every state has at most 65536 rows (21-bit thresholds, 16-bit local

@@ -383,8 +383,8 @@ assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
 
 
 def test_scan_kernel_is_chosen_by_the_table(gpu):
-    """BatchedPSRS._streams_apply without OFFSIM_SCAN_ROWS: a table whose largest state holds more than 3 % of the rows takes the window
-    kernel on permutations, one without such a state the row-packed kernel on streams; both give the oracle's results (child process:
+    """BatchedPSRS._streams_apply without OFFSIM_SCAN_ROWS: a table whose largest state holds more than 3 % of the rows, or a policy whose
+    acceptance is below 0.4, takes the window kernel on permutations, otherwise the row-packed kernel on streams; all give the oracle's results (child process:
     the suite itself forces the row-packed kernel, tests/conftest.py)."""
     import os, subprocess, sys
     code = r'''
@@ -396,11 +396,11 @@ from rl_offline_simulation_amd import synth
 from rl_offline_simulation_amd.table import TransitionTable
 from rl_offline_simulation_amd.evaluators import BatchedPSRS
 assert "OFFSIM_SCAN_ROWS" not in os.environ
-for nS, want in ((10, "k_eval_mc_win"), (120, "k_eval_mc_rows")):
-    e = synth.synth_iid(60000, nS, 3, seed=nS)
+for nS, nA, want in ((10, 2, "k_eval_mc_win"), (120, 2, "k_eval_mc_rows"), (120, 5, "k_eval_mc_win")):  # a hot state; neither; low acceptance
+    e = synth.synth_iid(60000, nS, nA, seed=nS)
     t0 = e["steps"] == 0
     table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
-    pi = synth.dirichlet_policy(nS, 3)
+    pi = synth.dirichlet_policy(nS, nA)
     seeds = [3, 4, 5, 6, 7]
     env = BatchedPSRS(table, len(seeds))
     env.reset_sampler(seeds, policy=table.policy_slots(pi))
