@@ -293,6 +293,7 @@ def run(a):
         else:
             dist.init_process_group(a.dist_backend)
     lib = _lib.load()
+    import ctypes as C
 
     R = a.rollouts
     strong = a.scaling == "strong"
@@ -324,8 +325,14 @@ def run(a):
         from rl_offline_simulation_amd.evaluators.psrs import rollout_resident_bytes
         per_rollout = rollout_resident_bytes(table, keyed=a.shuffle == "per_rollout")
         free_b, total_b = torch.cuda.mem_get_info(dev)
-        fit = int((free_b - (2 << 30)) // max(per_rollout, 1)) if a.shuffle == "per_rollout" else n_loc
+        # (room is left for the chunked shuffle's workspace -- chains of more than 65536 rows --, at most a tenth of what is free)
+        ws_b = min(int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), free_b // 10)
+        fit = int((free_b - (2 << 30) - ws_b) // max(per_rollout, 1)) if a.shuffle == "per_rollout" else n_loc
         tile = max(1, min(a.tile if a.tile > 0 else n_loc, n_loc, max(fit, 1)))
+        # tiles of ONE size (the last one is filled up with repeats of its last seed, whose results are dropped): a second batch size
+        # would be a second set of resident buffers
+        n_tiles = -(-n_loc // tile)
+        tile = -(-n_loc // n_tiles)
         assert a.shuffle != "per_rollout" or tile * per_rollout <= free_b, (tile, per_rollout, free_b)
         resident = tile * per_rollout if a.shuffle == "per_rollout" else per_rollout
         envs = {}
@@ -342,6 +349,9 @@ def run(a):
         def one_pass(record):
             for b in range(0, n_loc, tile):
                 sd = sd_all[b:b + tile]
+                n_real = len(sd)
+                if n_real < tile:
+                    sd = np.concatenate([sd, np.repeat(sd[-1:], tile - n_real)])
                 env = env_for(len(sd))
                 if record:
                     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -357,7 +367,7 @@ def run(a):
                     ev.append(("reset_sampler", e0, e1))
                     ev.append(("scan", e1, e2))
                 for k in acc:
-                    acc[k][b:b + len(sd)] = o[k]
+                    acc[k][b:b + n_real] = o[k][:n_real]
             if fill_full:  # rollout-sharded: every rank owns a slice of the seeds, the all-reduce assembles the [R,2] table
                 est = torch.zeros((R, 2), dtype=torch.float64, device=dev)
                 est[seed_lo:seed_hi, 0] = acc["sum_g"]
