@@ -390,6 +390,7 @@ struct ShcPlan {
 static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspace_bytes, bool plain) {
     ShcPlan p;
     if (shc_longest(t) == 0 || t->max_seg > (1ll << 23) || t->N0 > (1ll << 23) || !workspace || ((uintptr_t)workspace & 7u) != 0) return p;
+    if (t->n_slots + 1 > (SHC_HEADER_BYTES / 4 - 64)) return p;  // (the work list lives in the header)
     p.words = shc_block_words(t, &p.msg_cap, &p.lc_words, plain);
     p.n_wg = (workspace_bytes - SHC_HEADER_BYTES) / (p.words * 8);
     int dev = 0, cus = 256;

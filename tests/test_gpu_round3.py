@@ -327,6 +327,17 @@ for n, nS, R in shapes:
         perm = (out["1"].perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
         for k, sd in enumerate(seeds):
             assert np.array_equal(perm[k, :n], O.permutation(sd, n)), (n, sd)
+# more states than the kernel's work list holds (the permutation form takes any number): the in-place shuffle serves the long init queue
+os.environ["OFFSIM_SHUFFLE_CHUNKED"] = "1"
+e = synth.synth_iid(150000, 1000, 2, seed=5)
+table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], np.ones(150000, bool))
+env = BatchedPSRS(table, 2)
+env.reset_sampler([11, 12])
+torch.cuda.synchronize()
+assert L.load().offsim_async_faults() == 0
+ip = (env.state.init_perm.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+for k, sd in enumerate([11, 12]):
+    assert np.array_equal(ip[k, :150000], O.permutation(sd, 150000))
 print("ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OFFSIM_SHUFFLE_CHUNK=chunk)
