@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="plumbing test: several ranks share GPU 0 (use with --dist-backend gloo)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads-cap", type=int, default=64, help="host threads of the CPU baseline (each holds its own queues: 170 MB at 10 M rows)")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group and run the all-reduce of the per-seed estimates even with ONE "
+                                                              "rank (legal for RCCL): the only way a one-GPU box executes the collective leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configurations (C2 CartPole 1 M x 4096, C3 continuous_grid 10 M x 4096 "
+                                                              "with the MLP encoder) that the default single-GPU headline run appends under \"configs\"")
     ap.add_argument("--print-csrc-digest", action="store_true", help="print the digest of the kernel sources (recorded by tools/profile_bench.sh) and exit")
     return ap.parse_args()
 
@@ -212,7 +216,7 @@ def pmc_traffic(a, kernel, world):
     be read from inside the run).  Used only when that profile was taken with the kernel sources of THIS build
     (summary.json records their digest) and with this command; otherwise null."""
     default = (a.workload == "iid" and a.transitions == 10_000_000 and a.rollouts == 4096 and a.n_states == 162 and
-               a.n_actions == 2 and a.shuffle == "per_rollout" and world == 1)
+               a.n_actions == 2 and a.shuffle == "per_rollout" and world == 1 and not os.environ.get("OFFSIM_BENCH_TEST_SCALE"))
     if not default:
         return None, "no PMC profile for this command"
     dig = csrc_digest()
@@ -243,11 +247,14 @@ def make_log(a, seed, dev):
     from rl_offline_simulation_amd import synth
     N = a.transitions
     note = ""
+    t_gen = time.perf_counter()
     if a.workload == "cartpole":
         from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
         e = synth.cartpole_log(N, seed=seed)
         enc = CartpoleBoxEncoder()
+        t_e = time.perf_counter()
         e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
+        a.encode_s = time.perf_counter() - t_e
         a.n_states, a.n_actions = 162, 2
     elif a.workload == "grid":
         from rl_offline_simulation_amd.encoders import HOMEREncoder
@@ -259,10 +266,13 @@ def make_log(a, seed, dev):
                                                       "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2}, device=dev)
         t_e = time.perf_counter()
         e["z"], e["z_next"] = enc.encode(e["observations"]), enc.encode(e["next_observations"])
-        note = f", host-to-z encode {time.perf_counter() - t_e:.2f} s"
+        a.encode_s = time.perf_counter() - t_e
+        note = f", host-to-z encode {a.encode_s:.2f} s"
         a.n_states, a.n_actions = 25, 5
     else:
         e = synth.synth_iid(N, a.n_states, a.n_actions, seed=seed)
+        a.encode_s = 0.0
+    a.generate_s = time.perf_counter() - t_gen - a.encode_s
     return e, note
 
 
@@ -287,16 +297,30 @@ def run(a):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or a.force_dist
+    if use_pg:
+        if world == 1:  # (a one-rank group needs no launcher: rendezvous with itself)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
         if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(a.dist_backend)
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     lib = _lib.load()
     import ctypes as C
 
     R = a.rollouts
     strong = a.scaling == "strong"
+    # the default single-GPU headline command also reports the other BASELINE configurations that fit one GPU (C2, C3)
+    headline = (a.workload == "iid" and a.transitions == 10_000_000 and R == 4096 and a.n_states == 162 and a.n_actions == 2 and
+                a.shuffle == "per_rollout" and a.rng == "pcg64" and world == 1)
+    # OFFSIM_BENCH_TEST_SCALE = k (tests only): the same code path with every log k times shorter; the line says so (`test_scale`)
+    test_scale = max(1, int(os.environ.get("OFFSIM_BENCH_TEST_SCALE", "1")))
+    a.transitions //= test_scale
     # strong: every rank derives its shard from the same log; weak: shard g is its own log, generated from seed 20221107 + g
     e_full, enc_note = make_log(a, 20221107 + (0 if strong else rank), dev)
     if strong and world > 1:
@@ -307,15 +331,19 @@ def run(a):
     seeds = np.arange(R, dtype=np.uint64)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full):
+    def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full, pi=pi):
         """n_warm + n_timed passes of seeds[seed_lo:seed_hi] over the table of e_rank.  Returns the timing, the per-kernel HIP-event
         times and the per-seed results of the last pass."""
+        torch.cuda.synchronize()
+        t_ing = time.perf_counter()
         table = TransitionTable(e_rank["z"], e_rank["actions"], e_rank["rewards"], e_rank["z_next"], e_rank["terminals"],
                                 e_rank["action_distributions"], e_rank["steps"] == 0, device=dev)
+        torch.cuda.synchronize()
+        t_ing = time.perf_counter() - t_ing  # host columns -> device, group-by-state, gathers (once per log; outside the timed passes)
         pi_slots = table.policy_slots(pi)
         sd_all = seeds[seed_lo:seed_hi]
         n_loc = len(sd_all)
@@ -344,6 +372,7 @@ def run(a):
 
         acc = {k: torch.zeros(n_loc, dtype=dt, device=dev) for k, dt in (("sum_g", torch.float64), ("n_ep", torch.int64),
                                                                            ("steps", torch.int64), ("cand", torch.int64))}
+        local = {}
         ev = []  # (kind, start, stop) HIP events on the launch stream (torch's current stream is the stream handed to the C ABI)
 
         def one_pass(record):
@@ -374,8 +403,9 @@ def run(a):
                 est[seed_lo:seed_hi, 1] = acc["n_ep"].to(torch.float64)
             else:
                 est = torch.stack([acc["sum_g"], acc["n_ep"].to(torch.float64)], dim=1)
-            if world > 1:
-                allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096)
+            if use_pg:
+                local["est"] = est.clone() if world == 1 else None
+                allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096), on the device tensor
             return est
 
         for _ in range(n_warm):
@@ -388,7 +418,7 @@ def run(a):
         elapsed = time.perf_counter() - t_start
         el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tot = torch.stack([acc["steps"].sum(), acc["cand"].sum()]).to(torch.float64)
-        if world > 1:
+        if use_pg:
             dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         t_scan = sum(s.elapsed_time(t) for k, s, t in ev if k == "scan") * 1e-3
@@ -397,7 +427,8 @@ def run(a):
                    n_scan=sum(1 for k, _, _ in ev if k == "scan"), my_steps=float(acc["steps"].sum()), my_cand=float(acc["cand"].sum()),
                    est=est, acc={k: v.cpu().numpy() for k, v in acc.items()}, b_c=table.bytes_per_candidate, b_s=table.bytes_per_step,
                    rows=table.N, tile=tile, variant=env_for(tile).scan_variant() if a.rng == "pcg64" else "k_eval_mc", seg=(table.min_seg, table.max_seg),
-                   resident=int(resident), hbm_free=int(free_b), hbm_total=int(total_b))
+                   resident=int(resident), hbm_free=int(free_b), hbm_total=int(total_b), ingest_s=t_ing, est_local=local.get("est"))
+        _lib.check_async_faults()  # (the barrier synchronised: no kernel of these passes gave up a bounded wait)
         del envs, table
         torch.cuda.empty_cache()
         return res
@@ -412,6 +443,56 @@ def run(a):
                  "scan_s_per_pass": x["t_scan"], "reset_sampler_s_per_pass": x["t_reset"],
                  "what": "same job split the other way (SURVEY 8e primary axis): the whole log replicated on every GPU, R/N seeds per GPU, "
                          "all-reduce assembles the [R,2] table"}
+
+    coll = None
+    if use_pg:  # the collective alone: the [R,2] f64 all-reduce on the device tensor, HIP events around 20 of them
+        x = m["est"].clone()
+        allreduce_estimates(x)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        c0.record()
+        for _ in range(20):
+            allreduce_estimates(x)
+        c1.record()
+        torch.cuda.synchronize()
+        coll = {"backend": dist.get_backend(), "world": world, "device_tensor": bool(x.is_cuda), "bytes": int(x.numel() * 8),
+                "allreduce_us": c0.elapsed_time(c1) * 1e3 / 20,
+                "librccl_mapped": any("librccl" in ln for ln in open("/proc/self/maps")),
+                "unchanged_at_one_rank": (bool(torch.equal(m["est"], m["est_local"])) if world == 1 and m["est_local"] is not None else None)}
+
+    def extra_config(name, workload, transitions):
+        """One more BASELINE configuration on this GPU, same binary, same R: log generation (host), encoder forward (device), ingest,
+        1 warm-up + 2 timed passes, and its own parity check (the oracle on four seeds of the same table)."""
+        import copy
+        b = copy.copy(a)
+        b.workload, b.transitions = workload, transitions
+        e_c, _ = make_log(b, 20221107, dev)
+        pi_c = synth.dirichlet_policy(b.n_states, b.n_actions)
+        a_sh, a_rng = a.shuffle, a.rng
+        x = measure(e_c, 0, R, 1, 2, False, pi=pi_c)
+        b_c = x["b_c"] + 4
+        alg = x["my_cand"] * b_c + x["my_steps"] * x["b_s"]
+        out_c = {"workload": f"{workload}, {transitions} transitions x {R} rollouts, nS={b.n_states}, nA={b.n_actions}", "value": x["steps_pass"] * 2 / x["elapsed"],
+                 "unit": "simulated steps/s", "ms_per_step": x["elapsed"] / 2 * 1e3, "scan_s": x["t_scan"] / 2, "reset_s": x["t_reset"] / 2,
+                 "kernel": x["variant"], "rollout_tile": x["tile"], "acceptance": x["steps_pass"] / max(x["cand_pass"], 1.0),
+                 "buffer_consumed_frac": x["cand_pass"] / (R * transitions), "segment_rows_min_max": list(x["seg"]),
+                 "roofline": {"bound": "hbm", "achieved": alg * 2 / x["t_scan"] / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": alg * 2 / x["t_scan"] / 1e9 / 8000.0, "bytes_per_candidate": b_c, "bytes_per_step": x["b_s"]},
+                 "log_generate_s_host": b.generate_s, "encode_s": b.encode_s, "ingest_s": x["ingest_s"]}
+        if not a.no_parity_check:
+            ps = [sd for sd in PARITY_SEEDS if sd < R]
+            got = {sd: {k: (float(v[sd]) if k == "sum_g" else int(v[sd])) for k, v in x["acc"].items()} for sd in ps}
+            pc = parity_check(oracle_for(e_c), pi_c, a.gamma, ps, got, a_sh, 1234)
+            out_c["parity_ok"] = pc["ok"]
+            out_c["parity_max_abs_value_err"] = pc["max_abs_value_err"]
+            if not pc["ok"]:
+                sys.stderr.write(json.dumps(pc) + "\n")
+                raise SystemExit(f"bench.py: configuration {name}: the GPU results differ from the oracle on this table -- no number is reported")
+        return out_c
+
+    configs = None
+    if headline and not a.no_configs:
+        configs = {"C2": extra_config("C2", "cartpole", 1_000_000 // test_scale), "C3": extra_config("C3", "grid", 10_000_000 // test_scale)}
 
     if rank == 0:
         elapsed, t_scan, t_reset, n_scan = m["elapsed"], m["t_scan"], m["t_reset"], m["n_scan"]
@@ -454,6 +535,13 @@ def run(a):
         }
         if extra:
             out["rollout_sharded"] = extra
+        if coll:
+            out["collective"] = coll
+        if configs:
+            out["configs"] = configs
+        out["ingest_s"] = m["ingest_s"]
+        if test_scale > 1:
+            out["test_scale"] = test_scale
         base = None
         if not a.no_parity_check and a.shuffle != "table_order" and a.rng == "pcg64":  # (the reference has no unshuffled mode; the C oracle draws from PCG64)
             base = oracle_for(e)
@@ -467,7 +555,7 @@ def run(a):
             out["cpu_baseline"] = cpu_baseline(base or oracle_for(e), pi, a.gamma, a.cpu_sample_seconds, a.cpu_threads_cap)
         _REAL_STDOUT.write(json.dumps(out) + "\n")
         _REAL_STDOUT.flush()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

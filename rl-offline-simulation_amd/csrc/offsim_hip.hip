@@ -11,6 +11,7 @@
 // No CPU fallback lives here: without a HIP device every entry point returns OFFSIM_EHIP.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -324,10 +325,21 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
 // Fault bits raised by asynchronous kernels of this device since the last call (and cleared by it): OFFSIM_FAULT_SHUFFLE -- a role of
 // the shuffle's ring protocol gave up a bounded wait (the orders of that call are invalid); OFFSIM_FAULT_SCAN -- the same in the scan
 // (those rollouts also carry OFFSIM_ST_PROTOCOL).  Synchronise the stream the kernels ran on first.
+__global__ void k_fault_exchange(int32_t *out) { *out = atomicExch(&offsim::g_async_fault, 0); }
+
 extern "C" int offsim_async_faults(void) {
-    int32_t v = 0, zero = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(offsim::g_async_fault), sizeof(v)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: read failed%s");
-    if (v && hipMemcpyToSymbol(HIP_SYMBOL(offsim::g_async_fault), &zero, sizeof(zero)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: clear failed%s");
+    // read and clear in ONE atomic exchange on the device (a separate read and clear could lose a bit raised in between); the word
+    // is per device: callers that interleave several environments on one device attribute a fault to whatever they ran since their
+    // last call (include/offsim.h)
+    static int32_t *slot[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> hold(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OFFSIM_EHIP, "async_faults: no device%s");
+    if (!slot[dev] && hipMalloc((void **)&slot[dev], sizeof(int32_t)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: allocation failed%s");
+    hipLaunchKernelGGL(k_fault_exchange, dim3(1), dim3(1), 0, (hipStream_t)0, slot[dev]);
+    int32_t v = 0;
+    if (hipMemcpy(&v, slot[dev], sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: read failed%s");
     return v;
 }
 
@@ -341,8 +353,8 @@ extern "C" int offsim_shuffle_queues(const offsim_table *t, const uint64_t *seed
 // Keyed form of the chains that do not fit LDS (states of more than 65536 rows, stream format B): the global-memory variant has shuffled
 // grouped-row indices in place in the state's slice of dig_out; every position becomes {digest | local-row bits 16.., local-row low half}.
 __global__ void __launch_bounds__(256) k_big_keys(const uint32_t *__restrict__ seg_off, int64_t N, const uint32_t *__restrict__ dig32,
-                                                  uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out) {
-    const uint32_t s = blockIdx.y, r = blockIdx.z;
+                                                  uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out, uint32_t r0) {
+    const uint32_t s = blockIdx.y, r = r0 + blockIdx.z;
     const uint32_t beg = seg_off[s], len = seg_off[s + 1] - beg;
     if (len <= SHUF_CAP16) return;
     for (uint32_t k = blockIdx.x * 1024u + threadIdx.x; k < len && k < (blockIdx.x + 1u) * 1024u; k += 256u) {
@@ -464,10 +476,12 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
     if (rc || (!big && !chunked)) return rc;
     if (chunked) return shc_launch(p, t, seeds, n_perm, dig32, dig_out, loc_out, init_perm_out, nullptr, workspace, st);
-    if (n_perm > 65535) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: more than 65535 orders of a big-segment table per call%s");
-    hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)n_perm), dim3(256), 0, st,
-                       t->seg_off, t->N, dig32, dig_out, loc_out);
-    LAUNCH_CHECK();
+    for (int32_t r0 = 0; r0 < n_perm; r0 += 65535) {  // (gridDim.z holds at most 65535 orders)
+        const int32_t nz = n_perm - r0 < 65535 ? n_perm - r0 : 65535;
+        hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)nz), dim3(256), 0, st,
+                           t->seg_off, t->N, dig32, dig_out, loc_out, (uint32_t)r0);
+        LAUNCH_CHECK();
+    }
     return OFFSIM_OK;
 }
 

@@ -979,6 +979,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         // The state of a row (zz = state, ra = the address its entry was read from, w = the entry) is not copied at the end of a
         // step: even copies take it from (zz, ra, w) and leave the next one in (zn, rb, w2), odd copies the other way round;
         // the entry code fills both sets, the exits put it where the C++ code expects it.
+#ifdef ROWS_LOOP_V1  /* round 3's order: the next entry's read behind the row store (A/B builds only) */
+#define ROWS_EPI_WAIT
+#define ROWS_ENTRY_WAIT
 #define ROWS_STEP(LOGOFF, EPI, BACK, ZZ, RA, W, ZN, RN, WN)                                                                   \
             BACK ":\n\t"                                                                                                  \
             "s_waitcnt lgkmcnt(0)\n\t"                                   /* this look's entry and draw */                \
@@ -1008,6 +1011,46 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (behind the store: right also if it is this state) */ \
             "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"              /* log word: state left | candidates consumed << 26 */ \
             "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"
+#else
+#define ROWS_EPI_WAIT "s_waitcnt lgkmcnt(0)\n\t"   /* (a copy does not wait for its entry and draw itself) */
+#define ROWS_ENTRY_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+        /* Round 4: the read of the next look's entry is issued as soon as the next state is known -- it heads the step's dependent   */
+        /* chain (entry -> key -> three DPP minima -> next state -> entry), everything else (draw counter and the next draw's read,    */
+        /* the event test, the shifted row's store, the log word) is issued behind it, in the shadow of its LDS round trip.  The read  */
+        /* is therefore AHEAD of the row store: a row that stays in its state (next state == this one) would see the row before the   */
+        /* shift, so "same state" is one more event of the out-of-line path, which reads the entry again behind the store.  One test   */
+        /* covers all three: u = (next ^ this) - 1 is >= 0x3ff iff next == this, or next carries the done bit / is the all-ones key (else < 0x100). */
+#define ROWS_STEP(LOGOFF, EPI, BACK, ZZ, RA, W, ZN, RN, WN)                                                                   \
+            BACK ":\n\t"                                                 /* (this look's entry and draw have arrived: waited for below / at the entry / in ROWS_EPI) */ \
+            "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */                \
+            "v_and_or_b32 %[key], " W ", %[spay], %[lif]\n\t"            /* (lane + 1) << 26 | the digest's low bits: done << 10 | z_next (| local-row high bits) */ \
+            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
+            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"              /* (two instructions behind the one that wrote vcc, two ahead of the DPP read) */ \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
+            "v_and_b32 " ZN ", %[szm], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
+            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
+            "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (ahead of the store: wrong if it is this state -- an event) */ \
+            "v_add_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
+            "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
+            "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
+            "v_xad_u32 %[e], " ZN ", " ZZ ", -1\n\t"                      /* (next ^ this) - 1 */                         \
+            "v_cmp_lt_u32_e64 %[ev], %[srmask], %[e]\n\t"                /* same state, episode end, or the all-ones key of a row without a clear accept (<= 256 states: otherwise < 0x100) */ \
+            "v_sub_co_u32_sdwa %[tt], vcc, %[li4w], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
+            "v_cndmask_b32_e64 %[d], " W ", 0, vcc\n\t"                                                                   \
+            "v_bfi_b32 %[tt], 28, %[tt], " RA "\n\t"                     /* its address in this state's row */           \
+            "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
+            "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
+            /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
+            "ds_write_b32 %[tt], %[d]\n\t"                               /* the row, shifted */                          \
+            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"              /* log word: state left | candidates consumed << 26 */ \
+            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"                                                           \
+            "s_waitcnt lgkmcnt(2)\n\t"                                   /* the two reads; the two stores behind them may still be on their way (one wavefront's DS instructions execute in issue order) */
+#endif
         /* Out of line: the only event of the look is the end of an episode in some rows (psrs.py:249-269: env.reset() pops */   \
         /* the shuffled init queue).  The row's next initial states wait in its LDS ring; `left` says how many the loop may   */  \
         /* take before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed with */ \
@@ -1035,6 +1078,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
             "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"                                                               \
             "ds_read_b32 " WN ", " RN "\n\t"                                                                               \
+            ROWS_EPI_WAIT                                                                                                  \
             "s_branch " BACK "b\n\t"
         // an event the loop does not serve: nothing of copy I is committed, the row state goes where the C++ code expects it
 #define ROWS_OUT_A(OUT, I) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 2f\n\t"
@@ -1049,6 +1093,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_mov_b32 %[zn], %[zz]\n\t"                                 // both register sets hold the row state: any copy may be the first
             "v_mov_b32 %[rb], %[ra]\n\t"
             "v_mov_b32 %[w2], %[w]\n\t"
+            ROWS_ENTRY_WAIT
             "s_cmp_eq_u32 %[it], 0\n\t"
             "s_cbranch_scc1 100f\n\t"
             "s_getpc_b64 s[20:21]\n\t"                                   // = the address of the next instruction; the table starts 20 bytes behind it
@@ -1101,6 +1146,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             ROWS_OUT_A("308", "8") ROWS_OUT_B("309", "9") ROWS_OUT_A("310", "10") ROWS_OUT_B("311", "11")
             ROWS_OUT_A("312", "12") ROWS_OUT_B("313", "13") ROWS_OUT_A("314", "14") ROWS_OUT_B("315", "15")
             "22:\n\t"                                                    // event in an odd copy: its state is in (zn, rb, w2)
+            "s_waitcnt lgkmcnt(0)\n\t"                                   // (the early read of the next entry is on its way into w)
             "v_mov_b32 %[zz], %[zn]\n\t"
             "v_mov_b32 %[ra], %[rb]\n\t"
             "v_mov_b32 %[w], %[w2]\n\t"
@@ -1117,6 +1163,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             : "vcc", "scc", "memory", "s20", "s21", "s22", "s24", "s25");
 #undef ROWS_STEP
 #undef ROWS_EPI
+#undef ROWS_EPI_WAIT
+#undef ROWS_ENTRY_WAIT
 #undef ROWS_OUT_A
 #undef ROWS_OUT_B
 #undef ROWS_STEP_

@@ -24,8 +24,10 @@ def shard_episodes(episode_ids, rank, world):
 
 
 def allreduce_estimates(est):
-    """In-place SUM all-reduce of est[R,2] = (sum of returns, n episodes) per seed across ranks."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place SUM all-reduce of est[R,2] = (sum of returns, n episodes) per seed across ranks: on the device tensor itself
+    (backend "nccl" = RCCL over xGMI; gloo stages a device tensor through the host).  A process group of one rank still runs
+    the collective (legal for RCCL, and the only way a one-GPU box executes this leg); without a process group it is a no-op."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(est, op=dist.ReduceOp.SUM)
     return est
 

@@ -39,6 +39,15 @@ class HOMEREncoder:
         return (z, logits) if return_logits else z
 
     def encode(self, observations):
+        """homer.py:159-168.  float16 observations (config C5) cross the PCIe bus as float16 and are widened by the kernel -- the
+        reference's `.float()` (homer.py:163) is a cast on the device side too, and exact; every other dtype is cast to float32 on the
+        host as before.  `last_input_dtype` records which instance of the kernel ran."""
         dev = self.device or L.require_device()
-        x = torch.as_tensor(np.asarray(observations, dtype=np.float32)).to(dev)  # homer.py:163 casts to float
-        return self.encode_device(x).cpu().numpy().astype(np.int64)
+        obs = observations if isinstance(observations, torch.Tensor) else np.asarray(observations)
+        half = obs.dtype in (np.float16, torch.float16)
+        if isinstance(obs, torch.Tensor):
+            x = obs.to(device=dev, dtype=torch.float16 if half else torch.float32)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float16 if half else np.float32)).to(dev)
+        self.last_input_dtype = x.dtype
+        return self.encode_device(x.reshape(x.shape[0], -1)).cpu().numpy().astype(np.int64)

@@ -58,7 +58,12 @@ def _prob_mode(table, p_dtype):
 
 
 class BatchedPSRS:
-    """R PSRS environments sharing one logged-transition table."""
+    """R PSRS environments sharing one logged-transition table.
+
+    Every method only enqueues kernels on the current stream.  The sampler reset and the row-packed scan bound their
+    inter-wavefront waits and raise a device-wide fault word instead of hanging (include/offsim.h: offsim_async_faults): whoever
+    drives this class directly calls `check_faults()` once the results have been copied back (the host-facing drivers of this
+    module -- PSRS, evalMC_psrs, qlearn_psrs, expSARSA_psrs, evalmc_rollouts, VectorPSRS(strict=True) -- do)."""
 
     def __init__(self, table: TransitionTable, R: int, reject_mode=L.REJECT_DEFAULT):
         self.table, self.R = table, int(R)
@@ -75,6 +80,12 @@ class BatchedPSRS:
         self._perm_lazy = None
         self._pk_cache = None
         self._dig32 = None
+
+    @staticmethod
+    def check_faults():
+        """Synchronise the current stream and raise OffsimError if a kernel gave up a bounded wait since the last check."""
+        torch.cuda.current_stream().synchronize()
+        L.check_async_faults()
 
     # -- PSRS.reset_sampler (psrs.py:19-30) for all rollouts --
     def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None):
@@ -136,9 +147,10 @@ class BatchedPSRS:
     def _shuffle_workspace(self, n_orders=None):
         """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to
         four persistent workgroups per compute unit -- no more than there are chains (`n_orders` queue orders x (states + 1)), nor than
-        keeps each busy with about four of the longest -- or for
-        as many as 92 % of the free HBM holds (a workgroup's pools are ~22 bytes per row of the longest chain); None (the in-place
-        shuffle) when the table has no such chain, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit."""
+        keeps each busy with about four of the longest -- within a budget of the free HBM (`ws_budget_frac`, default 85 %, and never the
+        last `ws_keep_free` bytes, default 4 GiB: the policy's key buffer, rebuilt permutations, snapshots and outputs of the same
+        job are allocated later; a workgroup's pools are ~22 bytes per row of the longest chain).  None (the in-place shuffle) when the
+        table has no such chain, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit the budget."""
         t = self.table
         if max(t.max_seg, t.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
             return None
@@ -149,17 +161,22 @@ class BatchedPSRS:
         # (no more workgroups than keeps each busy with about four chains of the longest kind: a small job does not wait for gigabytes
         # of pools to be allocated)
         want = min(want, max(8, n_orders * getattr(t, "long_rows", t.N) // (4 * max(t.max_seg, t.N0, 1))))
-        have = getattr(self, "_ws", None)
-        if have is None or getattr(self, "_ws_wg", 0) < want:
+        if getattr(self, "_ws", None) is None or getattr(self, "_ws_wg", 0) < want:
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
             head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
             if one <= 0:
                 return None
-            self._ws = None
+            have_bytes = 0 if getattr(self, "_ws", None) is None else self._ws.numel()
+            self._ws = None  # (released first: what it held counts as free)
+            torch.cuda.empty_cache()
             free = torch.cuda.mem_get_info(t.device)[0]
-            n = min(want, max(0, (int(free * 0.92) - head) // max(one - head, 1)))
+            budget = min(int(free * getattr(self, "ws_budget_frac", 0.85)), free - int(getattr(self, "ws_keep_free", 4 << 30)))
+            n = min(want, max(0, (budget - head) // max(one - head, 1)))
+            if n < 1 and have_bytes:  # nothing bigger fits: what there was is put back
+                n = max(0, (have_bytes - head) // max(one - head, 1))
             if n < 1:
-                return have
+                self._ws_wg = want
+                return None
             self._ws = torch.empty(int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), int(n))), dtype=torch.uint8, device=t.device)
             self._ws_wg = want  # (what was asked for: a smaller grant is not asked for again)
         return self._ws
@@ -243,6 +260,24 @@ class BatchedPSRS:
         dg, lc = self._pack_streams(dig32, p)
         self._streams = dict(dig=dg, dig_stride=t.N if n_rows > 1 else 0, loc=lc, loc_stride=t.N if n_rows > 1 else 0, key=key,
                              format=self._stream_format())
+
+    def _rekey_streams(self, policy, key):
+        """reset_sampler(policy=A) laid the queue orders out as A's candidate streams and another policy is evaluated on the same
+        sampler state (the reference allows it: the queues just go on, psrs.py:241-271 takes any pi): the orders -- the local rows --
+        stay, the digest of every queue position is replaced IN PLACE by the new policy's, a few rollouts at a time (no second set
+        of resident buffers)."""
+        t = self.table
+        _, dig32 = self._policy_keys(policy, key=key)
+        base = self._seg_base()
+        fmt_b = self._stream_format() == L.STREAMS_B
+        step = max(1, (128 << 20) // max(t.N * 8, 1))
+        for b in range(0, self.R, step):
+            local = self._loc_buf[b:b + step, :t.N].to(torch.int64) & 0xFFFF
+            if fmt_b:
+                dg = self._dig_buf[b:b + step, :t.N].to(torch.int64)
+                local |= (((dg >> 8) & 3) | (((dg >> 11) & 0x1F) << 2)) << 16
+            self._dig_buf[b:b + step, :t.N] = self._pack_streams(dig32, local + base[None, :])[0]
+        self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=key, format=self._stream_format())
 
     def _pack_streams(self, dig32, p):
         """(dig, loc) streams of queue orders given as grouped rows p [..., N] (int64): the digest of the row at every position -- in
@@ -393,7 +428,10 @@ class BatchedPSRS:
             raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule, <= 256 states and the PCG64 stream")
         pkey = self._policy_key(pi_slots) if fast else None  # (once per call: a device tensor is copied to the host for it)
         if fast and not (self._streams is not None and self._streams["key"] == pkey):
-            self._derive_streams(pi_slots, key=pkey)  # small jobs: the streams are gathered from the permutations on the spot
+            if self.state.perm is None and self._perm_lazy == "streams":
+                self._rekey_streams(pi_slots, pkey)  # the orders exist only as another policy's streams: same orders, this policy's digests
+            else:
+                self._derive_streams(pi_slots, key=pkey)  # small jobs: the streams are gathered from the permutations on the spot
         rows = bool(fast) and self._streams is not None and self._streams["key"] == pkey
         if rows:  # the sampler reset laid the orders out as candidate streams for this policy: row-packed scan
             keys, _ = self._policy_keys(pi_slots, key=pkey)
@@ -403,8 +441,6 @@ class BatchedPSRS:
             L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
                                                     gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys, sm)
-        elif fast and self.state.perm is None and self._perm_lazy == "streams":
-            raise L.OffsimError("the queue orders were laid out for another policy (reset_sampler(policy=...)): call reset_sampler again")
         elif fast:
             keys = self.compile_policy(pi_d)
             L.check(L.load().offsim_eval_mc_keys(C.byref(t.c), C.byref(self.state.c), L.ptr(keys), float(gamma), L.ptr(gp),
@@ -579,10 +615,18 @@ class PSRS:
             seed = int.from_bytes(os.urandom(8), "little")  # default_rng(None): fresh OS entropy
         self._sampler_seed = int(seed)
         self._env.reset_sampler([seed], SHUFFLE_PER_ROLLOUT)
+        self._fault_check = True  # the shuffle bounds its waits: looked at where the host next synchronises (reset / step)
+
+    def _check_faults(self):
+        """After a host synchronisation: did the sampler reset give up a bounded wait (include/offsim.h: offsim_async_faults)?"""
+        if getattr(self, "_fault_check", False):
+            self._fault_check = False
+            L.check_async_faults()
 
     # -- psrs.py:32-37 (the seed argument is ignored there too) --
     def reset(self, seed=None):
         row = int(self._env.reset().cpu()[0])
+        self._check_faults()
         if row < 0:
             self.s = None
             return None
@@ -606,6 +650,7 @@ class PSRS:
                 if not self._reject_func(p_new, self._p_of(row), self._a_of(row)):
                     self._env.set_state(torch.tensor([self.table.slot_of(self._zn[row])]))
                     break
+        self._check_faults()
         if status == L.ST_KEYERROR:
             raise KeyError(z)
         if status in (L.ST_EXHAUSTED, L.ST_INACTIVE):
@@ -713,6 +758,8 @@ def evalMC_psrs(env, n_episodes, pi, gamma):
     n_ep = int(min(n_episodes, t.N0 + 1))
     o = env._env.eval_mc(t.policy_slots(pi), gamma, n_ep, ep_cap=max(n_ep, 1))
     status = int(o["status"].cpu()[0])
+    env._fault_check = False
+    L.check_async_faults()  # (the copy above synchronised the stream)
     if status == L.ST_KEYERROR:
         raise KeyError(t.z_of(env._env.state.cur_slot.cpu()[0]))
     ne, nl = int(o["n_ep"].cpu()[0]), int(o["n_len"].cpu()[0])
@@ -843,6 +890,8 @@ def _td_run(env, what, n_episodes, gamma, alpha, Q_init, save_Q, mode, kind, pi_
                          alpha_ep=a_tab, epsilon_ep=e_tab if behaviour == L.BEHAVIOUR_EPS_GREEDY else None,
                          snap_cap=cap if save_Q else 0, snap_stride=1, tie_mt=mt)
     status = int(o["status"].cpu()[0])
+    env._fault_check = False
+    L.check_async_faults()  # (the copy above synchronised the stream)
     if ties:
         w = o["tie_mt"].cpu().numpy().view(np.uint32)[0]
         np.random.set_state(("MT19937", w[:624].copy(), int(w[624]), st[3], st[4]))

@@ -85,6 +85,13 @@ class VectorPSRS:
     def reset_sampler(self, seeds):
         self.env.reset_sampler(seeds)
         self.alive.zero_()
+        if self.strict:  # (strict mode synchronises with the host anyway: a sampler reset that gave up a bounded wait raises here)
+            self.check_faults()
+
+    def check_faults(self):
+        """Synchronise and raise OffsimError if the sampler reset gave up a bounded wait (include/offsim.h: offsim_async_faults).  With
+        strict=False nothing synchronises with the host, so the caller does this once after reset_sampler (or whenever it reads results)."""
+        self.env.check_faults()
 
     def reset(self, mask=None):
         """PSRS.reset (psrs.py:32-37) for the environments in `mask` (all if None).  Returns (obs [R, ...], alive [R])."""

@@ -81,7 +81,7 @@ def test_c3_continuous_grid_learned_encoder(gpu):
     o2 = env.eval_mc(table.policy_slots(pi), 0.95)
     torch.cuda.synchronize()
     import os
-    assert env.scan_variant() == "k_eval_mc_rows" or os.environ.get("OFFSIM_SCAN_ROWS", "1") == "0"  # (the variant matrix of test_gpu_edges.py)
+    assert env.scan_variant() == "k_eval_mc_rows" or os.environ.get("OFFSIM_SCAN_ROWS", "1") in ("0", "auto")  # (the variant matrix of test_gpu_edges.py)
     for k in ("steps", "cand", "n_ep", "sum_g"):
         assert torch.equal(o2[k], o[k]), k
 
@@ -136,6 +136,7 @@ def test_c5_encoder_into_fp16_table_end_to_end(gpu):
     enc = HOMEREncoder(dO, nA, nZ, H, state_dict={"obs_encoder.0.weight": W1, "obs_encoder.0.bias": b1,
                                                   "obs_encoder.2.weight": W2, "obs_encoder.2.bias": b2})
     z, zn = enc.encode(obs), enc.encode(nobs)
+    assert enc.last_input_dtype == torch.float16  # the fp16-input instance of the MFMA kernel ran: the observations were not widened on the host
     zo, lo = O.mlp_encode(obs.astype(np.float32), W1, b1, W2, b2)
     top2 = np.sort(lo, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 1e-4

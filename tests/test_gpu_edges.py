@@ -156,21 +156,25 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
             assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
 
 
-@pytest.mark.parametrize("variant", ["rows_single", "win"])
+@pytest.mark.parametrize("variant", ["rows_single", "win", "auto"])
 def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
     """The fast path of eval_mc has three bit-identical forms: csrc/scan_rows.hpp with a helper wavefront per chain wavefront
     (four rollouts per wavefront, candidate streams: the default wherever it applies, so the whole in-process suite runs on
     it), the same kernel as a single wavefront (OFFSIM_ROWS_HELPER=0; also what every call with trace outputs runs), and
     csrc/scan_win.hpp on queue permutations (OFFSIM_SCAN_ROWS=0).  The switches are read per process: the golden-fixture
-    parity tests, the config tests, the round-2 tests and the edge cases of this file run again in a child process for each."""
+    parity tests, the config tests, the round-2 tests and the edge cases of this file run again in a child process for each.
+    "auto" is the PRODUCT's own choice (OFFSIM_SCAN_ROWS=auto: BatchedPSRS._streams_apply picks the kernel by the table, which the
+    suite otherwise overrides, tests/conftest.py): the parity, config and edge files once more, whatever kernel each table gets."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
     if variant == "win":
         env["OFFSIM_SCAN_ROWS"] = "0"
+    elif variant == "auto":
+        env["OFFSIM_SCAN_ROWS"] = "auto"
     else:
         env["OFFSIM_ROWS_HELPER"] = "0"
-    files = ["test_gpu_parity.py", "test_gpu_configs.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant != "win" else [])
+    files = ["test_gpu_parity.py", "test_gpu_configs.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant == "rows_single" else [])
     r = subprocess.run([sys.executable, "-m", "pytest"] + [os.path.join(here, f) for f in files] +
                        ["-m", "gpu", "-x", "-q", "-k", "not every_scan_variant and not headline_table_size and not two_ranks"],
                        env=env, capture_output=True, text=True, timeout=1800)
@@ -190,7 +194,7 @@ def _compare_untraced(e, pi, gamma, seeds, gpu, t0=None, n_episodes=None):
     o = env.eval_mc(table.policy_slots(pi), gamma, n_episodes=n_episodes, ep_cap=table.N0 + 1)
     torch.cuda.synchronize()
     import os
-    if os.environ.get("OFFSIM_SCAN_ROWS") != "0":
+    if os.environ.get("OFFSIM_SCAN_ROWS") not in ("0", "auto"):
         assert env.scan_variant() == "k_eval_mc_rows"  # (the candidate streams were derived: this ran the row-packed kernel)
     ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
     for i, s in enumerate(seeds):

@@ -219,15 +219,16 @@ def _rank_main(rank, world, port, out_path):
         return torch.stack([o["sum_g"], o["n_ep"].to(torch.float64)], dim=1)
 
     # (1) log sharded by episode, every seed on every shard
-    est = evaluate(shard_episodes(e["episode_ids"], rank, world), seeds).cpu()
+    est = evaluate(shard_episodes(e["episode_ids"], rank, world), seeds)  # (stays on the device: the collective takes the device tensor)
     mine = est.clone()
     allreduce_estimates(est)
+    assert est.is_cuda
     # (2) rollouts sharded, table replicated
     lo, hi = shard_rollouts(len(seeds), rank, world)
-    full = torch.zeros((len(seeds), 2), dtype=torch.float64)
-    full[lo:hi] = evaluate(np.ones(len(e["z"]), bool), seeds[lo:hi]).cpu()
+    full = torch.zeros((len(seeds), 2), dtype=torch.float64, device=dev)
+    full[lo:hi] = evaluate(np.ones(len(e["z"]), bool), seeds[lo:hi])
     allreduce_estimates(full)
-    np.savez(out_path + f".{rank}.npz", est=est.numpy(), mine=mine.numpy(), full=full.numpy())
+    np.savez(out_path + f".{rank}.npz", est=est.cpu().numpy(), mine=mine.cpu().numpy(), full=full.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -386,10 +386,11 @@ assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
     pi = t.policy_slots(synth.dirichlet_policy(1, 2))
     a, b = BatchedPSRS(t, 3), BatchedPSRS(t, 3)
     b._ws = torch.empty(8192, dtype=torch.uint8, device=gpu)  # header + 4 KB: no pools
+    b._ws_wg = 1 << 30  # (what _shuffle_workspace remembers having asked for: it keeps this workspace instead of allocating a full one)
     a.reset_sampler([7, 8, 9], policy=pi)
     b.reset_sampler([7, 8, 9], policy=pi)
     torch.cuda.synchronize()
-    assert a._ws.numel() > (1 << 20) and L.load().offsim_async_faults() == 0
+    assert a._ws.numel() > (1 << 20) and b._ws.numel() == 8192 and L.load().offsim_async_faults() == 0  # a: chunked kernel, b: in place
     assert torch.equal(a._dig_buf, b._dig_buf) and torch.equal(a._loc_buf, b._loc_buf) and torch.equal(a._init_perm_buf, b._init_perm_buf)
 
 

@@ -1,0 +1,117 @@
+"""Round-4 GPU tests: a second policy on the same sampler state (streams re-keyed in place), the RCCL leg on one rank, the fault
+word reaching the drop-in drivers, the bench line's extra configurations."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from rl_offline_simulation_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("nS,N", [(20, 40_000), (2, 180_000)])  # stream format A; format B (states of more than 65536 rows)
+def test_second_policy_on_the_same_sampler_state_rekeys_the_streams(nS, N, gpu):
+    """reset_sampler(policy=A) writes the queue orders as A's candidate streams; evaluating policy B afterwards on the same sampler
+    state is what the reference allows (evalMC_psrs takes any pi, the queues just go on: psrs.py:241-271).  The streams' digests
+    are replaced in place (BatchedPSRS._rekey_streams) and the row-packed kernel goes on -- against the oracle doing the same."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(N, nS, 3, seed=nS + 5)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    pa, pb = synth.dirichlet_policy(nS, 3, seed=1), synth.dirichlet_policy(nS, 3, seed=2)
+    seeds = [3, 4, 5, 6, 7]
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds, policy=table.policy_slots(pa))
+    assert env._streams is not None and env.state.perm is None
+    o1 = env.eval_mc(table.policy_slots(pa), 0.97, n_episodes=25, ep_cap=table.N0 + 1)
+    o1 = {k: v.clone() for k, v in o1.items() if isinstance(v, torch.Tensor)}
+    o2 = env.eval_mc(table.policy_slots(pb), 0.97, ep_cap=table.N0 + 1)  # (automatic mode: used to raise "laid out for another policy")
+    torch.cuda.synchronize()
+    L.check_async_faults()
+    assert env.scan_variant() == "k_eval_mc_rows" and env.state.perm is None
+    ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    for i, sd in enumerate(seeds):
+        ora.reset_sampler(sd)
+        for o, ref in ((o1, ora.evalmc(25, pa, 0.97)), (o2, ora.evalmc(10 ** 9, pb, 0.97))):
+            ne = int(o["n_ep"][i])
+            assert int(o["steps"][i]) == ref["steps"] and int(o["cand"][i]) == ref["candidates"] and ne == len(ref["Gs"]), (i, sd)
+            assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(900)
+def test_rccl_executes_the_allreduce_of_the_estimates_on_one_rank(gpu):
+    """The multi-GPU leg's collective on the hardware this box has: `bench.py --force-dist` creates the process group with backend
+    "nccl" (= RCCL) for its ONE rank (device_id = cuda:0) and runs measure()'s all-reduce of the [R,2] f64 device tensor in every
+    pass; a one-rank SUM leaves the table as it was, librccl is mapped into the process, and the line still passes its parity check
+    against the oracle.  (Child process: nothing here re-execs after the GPU is initialised.)"""
+    out = _bench(["--transitions", "300000", "--rollouts", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--force-dist"])
+    c = out["collective"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["device_tensor"] and c["librccl_mapped"], c
+    assert c["unchanged_at_one_rank"] is True and c["bytes"] == 64 * 2 * 8 and c["allreduce_us"] > 0
+    assert out["parity_check"]["ok"] and out["n_gpus"] == 1
+
+
+def test_drop_in_drivers_raise_when_the_sampler_reset_gave_up_a_wait(gpu):
+    """a shuffle role that gives up a bounded wait voids the orders of that call and raises only a device-wide fault
+    word.  The host-facing drivers look at it where they synchronise anyway: with the fault-injection build (role A of the shuffle
+    never starts, variants/lib_fault.so) PSRS.from_arrays -- reset_sampler() then reset(), psrs.py:13-14 -- raises OffsimError instead
+    of serving a void order, and so does VectorPSRS(strict=True).reset_sampler; the word is read and cleared by ONE atomic exchange."""
+    lib = os.path.join(ROOT, "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
+                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from rl_offline_simulation_amd import synth, _lib as L
+from rl_offline_simulation_amd.evaluators import PSRS, evalMC_psrs
+e = synth.synth_iid(5000, 5, 2, seed=1)
+try:
+    PSRS.from_arrays(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+    print("NO ERROR")
+except L.OffsimError as ex:
+    print("RAISED", "bounded wait" in str(ex))
+assert L.load().offsim_async_faults() == 0  # read and cleared
+print("ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OFFSIM_LIB=lib), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RAISED True" in r.stdout and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_carries_the_extra_configurations(gpu):
+    """bench.py appends C2 (CartPole, box encoder) and C3 (continuous_grid, MLP encoder on MFMA) to the headline line, each with its
+    own oracle parity check.  Exercised here at a reduced headline size through the same code (the default sizes run in the driver's
+    own bench call): OFFSIM_BENCH_CONFIG_SCALE shrinks the two logs."""
+    out = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env_extra={"OFFSIM_BENCH_TEST_SCALE": "50"}, timeout=900)
+    cfg = out["configs"]
+    assert set(cfg) == {"C2", "C3"}
+    for k in ("C2", "C3"):
+        assert cfg[k]["parity_ok"] is True and cfg[k]["value"] > 0 and cfg[k]["scan_s"] > 0 and cfg[k]["kernel"].startswith("k_eval_mc")
+    assert out["parity_check"]["ok"]
