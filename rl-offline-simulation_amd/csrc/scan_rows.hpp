@@ -340,8 +340,31 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         prefetch_step();  // entries [ic0, ic0 + 16) are stored, the rows of the next 16 requested
     }
 
+#ifdef OFFSIM_ROWS_PROF
+    uint64_t pf_fast = 0, pf_slow = 0, pf_tick = 0, pf_nslow = 0, pf_t0 = 0, pf_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t1 = 0;
+#define PF_START() pf_t0 = __builtin_amdgcn_s_memtime()
+#define PF_ADD(x) x += __builtin_amdgcn_s_memtime() - pf_t0
+#define PF_PH(k) { const uint64_t _n = __builtin_amdgcn_s_memtime(); pf_ph[k] += _n - pf_t1; pf_t1 = _n; }
+#define PS_T1() pf_t1 = __builtin_amdgcn_s_memtime()  /* stamps of the chain's slow iterations: chain slots 3-6, 8, 9 (the helper's own use of them is in its own registers) */
+#define PS(k) PF_PH(k)
+#else
+#define PF_PH(k)
+#define PF_START()
+#define PF_ADD(x)
+#define PS_T1()
+#define PS(k)
+#endif
     // ---- per-row state ----
     uint32_t log_a = rbase + RO_LOG;  // the step log of the current tick (HELPER: alternates between RO_LOG and RO_LOG2)
+    // The chain keeps the tick's step log in a REGISTER, lane = step (round 4): a step's word is merged into its lane under a lane mask
+    // (one v_cndmask in the hand-scheduled loop instead of a 16-cycle LDS store per step), the tick hands the sixteen words over with one
+    // store.  last_log: the word of the most recent step that was logged outside the loop (the loop's first copy writes the log of the
+    // step before it from (key, state left) of that step; handed last_log in both, it rewrites the same word).
+    uint32_t elog = 0, last_log = 0;
+    auto log_step = [&](uint32_t it, uint32_t word) __attribute__((always_inline)) {
+        elog = li == it ? word : elog;
+        last_log = word;
+    };
     uint32_t logh_a = rbase + RO_LOGH;  // ... and its side bytes (format B: local-row high bits of the steps logged in the long form)
     uint32_t z = 0;  // current state slot
     uint32_t n_dry = 0, n_tie = 0, n_tick = 0, n_late = 0, n_miss = 0, n_req = 0;
@@ -400,7 +423,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // the step's bookkeeping for a clear accept of window entry k1-1 with payload `key`
     auto commit = [&](uint32_t key, uint32_t k1, uint32_t it) __attribute__((always_inline)) {
         c += k1;
-        LV32(log_a + it * 4u) = rows_log_word(z, key & 0x400u, k1);
+        log_step(it, rows_log_word(z, key & 0x400u, k1));
         if (fmt_b) lds_w16(logh_a + it * 2u, rows_loc_hi(key));
         const uint32_t k1x4 = k1 << 2;
         LV32(((li4w - k1x4) & 28u) | (ra - li4w)) = li4w < k1x4 ? ROWS_EMPTY : w;  // (lanes 8..15 repeat the stores of lanes 0..7)
@@ -441,6 +464,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint32_t nv = rem < in_sector ? rem : in_sector;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
+            PS(5);
+#ifdef OFFSIM_ROWS_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(dg) : "memory");
+#endif
+            PS(6);
             const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> F.tshift;
             bool ok = valid && k21 <= (dg >> F.tshift);
             if (ok && k21 == (dg >> F.tshift)) {  // tie at the digest's resolution: k53 of draw c+li against the full T
@@ -458,7 +486,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint32_t k1 = (fk >> 16) + 1u;
             c += k1;
             const uint32_t cz1 = cz + k1;
-            LV32(log_a + it * 4u) = rows_log_word(z, acc & 0x400u, popped + k1);
+            log_step(it, rows_log_word(z, acc & 0x400u, popped + k1));
             if (fmt_b) lds_w16(logh_a + it * 2u, rows_loc_hi(acc));
             const uint32_t keep = nv - k1 < ROWS_W ? nv - k1 : ROWS_W;  // the candidates behind it become the window
             if (li < 8u) LV32(win_a + z * 32u + li4) = ROWS_EMPTY;
@@ -478,6 +506,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // candidate the window holds is a clear reject (or it holds none), they are consumed and the exact look starts behind them.
     auto exact_step = [&](uint32_t it, bool amb) __attribute__((always_inline)) {
         const uint32_t hv = held(w), ld = LV32(land_a + z * 4u);
+        PS(4);
         if (amb) {
             n_tie++;
             direct(it, ld - hv, 0u);
@@ -502,16 +531,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);  // enough for the rest of the tick (looks of <= 8)
     };
 
-#ifdef OFFSIM_ROWS_PROF
-    uint64_t pf_fast = 0, pf_slow = 0, pf_tick = 0, pf_nslow = 0, pf_t0 = 0, pf_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t1 = 0;
-#define PF_START() pf_t0 = __builtin_amdgcn_s_memtime()
-#define PF_ADD(x) x += __builtin_amdgcn_s_memtime() - pf_t0
-#define PF_PH(k) { const uint64_t _n = __builtin_amdgcn_s_memtime(); pf_ph[k] += _n - pf_t1; pf_t1 = _n; }
-#else
-#define PF_PH(k)
-#define PF_START()
-#define PF_ADD(x)
-#endif
     // ---- reward pipeline, three ticks deep so that no tick waits on HBM; lane = step of the tick.  R1 (tick k): request the
     // local row (loc stream) and the discount factor of the steps of tick k; R2 (k+1): request their rewards; R3 (k+2): the
     // in-order discounted sums (bit-exact Gs).  Runs in the chain wavefront's tick, or in the helper wavefront (HELPER).
@@ -866,7 +885,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
-            le = LV32(log_a + li4);
+            le = elog;  // (single wavefront: the log never leaves the registers)
             in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
         }
         PF_PH(0);
@@ -915,6 +934,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
             // order) -- BEHIND the landing: the helper aims its next requests at the windows' ends as it finds them, and a
             // request aimed at an end that is about to move is a request lost
+            LV32(log_a + li4) = elog;  // the tick's sixteen log words, lane = step
             LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
             LV32(sync_a + SY_C) = c;
             if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
@@ -965,206 +985,383 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         }
         uint32_t c4 = (c << 2) + li4w;  // draw counter, as the byte offset of this lane's ring slot
         uint32_t zz = z;
-        uint32_t key, d, tt, nrd, e, zn, rb, w2;
+        uint32_t key = last_log, key2, d, tt, nrd, e, zn, rb, w2;
         uint64_t amb, ev;
-        // One copy of the step; the loop body is the sixteen steps of a tick, copy i writing log word i (immediate offset), so
-        // there is neither a step counter nor a back edge, and the loop is entered at copy `it` through a branch table.
-        // What a step costs is the sum of what its instructions hold the wavefront for (tools/micro/issue.hip: VALU / SALU 4.4
-        // cycles, three-operand VALU 5.3, a DS instruction 16, a branch not taken ~10), so the step is made of as few of them as
-        // the algorithm allows, four DS instructions among them: the next draw's read (its address needs only the number of
-        // candidates consumed), the row store, the next entry's read BEHIND it (the next state may be this one) and the log
-        // word.  The chain keeps no cursor: a queue position is land - (entries held), worked out where it is needed (tick,
-        // exact path).  The one branch of a step leaves for every event at once: a lane near a tie, a row without a clear
-        // accept, the end of an episode.
+        const uint32_t gen4 = gen << 2;  // draws known to be in the ring (x 4, like c4)
+        // One copy of the step; the loop body is the sixteen steps of a tick, copy i logging step i, so there is neither a step
+        // counter nor a back edge, and the loop is entered at copy `it` through a branch table.
+        // What a step costs is the SUM of what its instructions hold the wavefront for (tools/micro/issue.hip: VALU / SALU 4.3
+        // cycles, three-operand VALU 5.2, a DS instruction 16, a branch not taken ~7; tools/micro/step_loop.hip runs this very
+        // loop in isolation and reproduces the sum to a few cycles): the step is issue-bound, so it is made of as few
+        // instructions as the algorithm allows.  Round 4:
+        //   * THREE DS instructions instead of four: the entry's read, the draw's read, the shifted row's store.  The log word
+        //     goes into a register (elog, lane = step) under the lane mask of its step, in the DPP wait states of the NEXT copy
+        //     (the state left and the key of a step survive until then: the register sets alternate);
+        //   * the entry's read is issued as soon as the next state is known and the copy waits for the two reads only
+        //     (lgkmcnt(1): the store behind them may still be on its way; one wavefront's DS instructions execute in issue
+        //     order).  The read is therefore AHEAD of the row store: a row that stays in its state would see the row before the
+        //     shift, so "same state" is one more event of the out-of-line path, which reads the entry again behind the store.
+        //     One test covers it together with the episode end and the row without a clear accept: u = (next ^ this) - 1 is
+        //     >= 0x3ff iff next == this or next carries the done bit / is the all-ones key, and < 0x100 otherwise (<= 256 states);
+        //   * the wait states of the three DPP minima hold the exact-look test and the log of the previous step;
+        //   * a row WITHOUT a clear accept (its window is dry, or all its entries were rejected: 2 % of the iterations) no longer
+        //     sends the wavefront through the compiled exact path (~2800 cycles of divergent C++ per event): label 50 serves it
+        //     here -- the held entries are consumed, the candidates up to the end of the head's 64-byte sector come straight from the stream, the same biased
+        //     compare picks the first clear accept, the window becomes the candidates behind it -- and the loop is entered again
+        //     at the next copy.  Whatever is not plain (a lane near a tie, the queue's last sixteen rows, draws running low,
+        //     sixteen rejections in a row, no initial state left, stream format B) leaves for the C++ path with nothing committed.
+        // Measured in isolation (step_loop.hip, alone / next to a busy partner wavefront): round 3's step 200 / 227 cycles, early
+        // read 177 / 202, this one 162 / 185.
+        // The chain keeps no cursor: a queue position is land - (entries held), worked out where it is needed (tick, exact
+        // path).  The one branch of a step leaves for every event at once.
         // The state of a row (zz = state, ra = the address its entry was read from, w = the entry) is not copied at the end of a
-        // step: even copies take it from (zz, ra, w) and leave the next one in (zn, rb, w2), odd copies the other way round;
-        // the entry code fills both sets, the exits put it where the C++ code expects it.
-#ifdef ROWS_LOOP_V1  /* round 3's order: the next entry's read behind the row store (A/B builds only) */
-#define ROWS_EPI_WAIT
-#define ROWS_ENTRY_WAIT
-#define ROWS_STEP(LOGOFF, EPI, BACK, ZZ, RA, W, ZN, RN, WN)                                                                   \
-            BACK ":\n\t"                                                                                                  \
-            "s_waitcnt lgkmcnt(0)\n\t"                                   /* this look's entry and draw */                \
+        // step: even copies take it from (zz, ra, w) and leave the next one in (zn, rb, w2), odd copies the other way round, and
+        // likewise the key (even copies: key, odd copies: key2); the entry code fills both sets, the exits put everything where
+        // the C++ code expects it.  The first copy after the entry logs "the step before it" from what the entry code put into
+        // its registers -- last_log, split so that the copy rebuilds exactly that word.
+        // Registers private to the block (clobbered): v110 = this lane's window slot x 4, v111 = (slot + 1) << 26, v112..v116 =
+        // the format's constants (payload mask, next-state mask, exact-look band, ring mask, log mask), v117..v127 temporaries.
+#define ROWS_STEP(EPI, BACK, ZZ, RA, W, ZN, RN, WN, KEY, KEYP, LMSH)                                                          \
+            BACK ":\n\t"                                                 /* (this look's entry and draw have arrived: waited for at the end of the copy before / at the entry / in ROWS_EPI) */ \
             "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */                \
-            "v_and_or_b32 %[key], " W ", %[spay], %[lif]\n\t"            /* (lane + 1) << 26 | the digest's low bits: done << 10 | z_next (| local-row high bits) */ \
-            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
-            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"              /* (two instructions behind the one that wrote vcc, two ahead of the DPP read) */ \
+            "v_and_or_b32 " KEY ", " W ", v112, v111\n\t"                /* (lane + 1) << 26 | the digest's low bits: done << 10 | z_next (| local-row high bits) */ \
+            "v_cmp_le_u32_e64 %[amb], v114, %[d]\n\t"                    /* the draw is above the entry by <= 17 units of T21: exact look */ \
+            "v_cndmask_b32_e64 " KEY ", " KEY ", -1, vcc\n\t"            /* (gfx940+: two instructions between the VALU that wrote vcc and this read of it) */ \
+            "v_and_or_b32 %[e], " KEYP ", v116, " ZN "\n\t"              /* wait state 1 of 2 ahead of the DPP read: log word of the PREVIOUS step: candidates consumed << 26 | done << 10 | state left (still in the set this copy is about to overwrite) */ \
+            "s_lshl_b64 s[22:23], s[26:27], " LMSH "\n\t"                /* the lanes that hold the previous step's log word */ \
+            "v_min_u32_dpp " KEY ", " KEY ", " KEY " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                  \
+            "v_cndmask_b32_e64 %[elog], %[elog], %[e], s[22:23]\n\t"                                                      \
+            "s_nop 0\n\t"                                                                                                 \
+            "v_min_u32_dpp " KEY ", " KEY ", " KEY " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                  \
             "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
-            "v_and_b32 " ZN ", %[szm], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
-            "v_add_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
-            "v_cmp_lt_u32_e64 %[ev], %[srmask], " ZN "\n\t"              /* episode end, or the all-ones key of a row without a clear accept (states are < 0x3fc) */ \
-            "v_sub_co_u32_sdwa %[tt], vcc, %[li4w], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
-            "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
-            "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
-            "v_cndmask_b32_e64 %[d], " W ", 0, vcc\n\t"                                                                   \
-            "v_bfi_b32 %[tt], 28, %[tt], " RA "\n\t"                     /* its address in this state's row */           \
-            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
-            "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
-            "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
-            /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
-            "ds_write_b32 %[tt], %[d]\n\t"                               /* the row, shifted */                          \
-            "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (behind the store: right also if it is this state) */ \
-            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"              /* log word: state left | candidates consumed << 26 */ \
-            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"
-#else
-#define ROWS_EPI_WAIT "s_waitcnt lgkmcnt(0)\n\t"   /* (a copy does not wait for its entry and draw itself) */
-#define ROWS_ENTRY_WAIT "s_waitcnt lgkmcnt(0)\n\t"
-        /* Round 4: the read of the next look's entry is issued as soon as the next state is known -- it heads the step's dependent   */
-        /* chain (entry -> key -> three DPP minima -> next state -> entry), everything else (draw counter and the next draw's read,    */
-        /* the event test, the shifted row's store, the log word) is issued behind it, in the shadow of its LDS round trip.  The read  */
-        /* is therefore AHEAD of the row store: a row that stays in its state (next state == this one) would see the row before the   */
-        /* shift, so "same state" is one more event of the out-of-line path, which reads the entry again behind the store.  One test   */
-        /* covers all three: u = (next ^ this) - 1 is >= 0x3ff iff next == this, or next carries the done bit / is the all-ones key (else < 0x100). */
-#define ROWS_STEP(LOGOFF, EPI, BACK, ZZ, RA, W, ZN, RN, WN)                                                                   \
-            BACK ":\n\t"                                                 /* (this look's entry and draw have arrived: waited for below / at the entry / in ROWS_EPI) */ \
-            "v_sub_co_u32 %[d], vcc, " W ", %[kt]\n\t"                   /* borrow: not a clear accept */                \
-            "v_and_or_b32 %[key], " W ", %[spay], %[lif]\n\t"            /* (lane + 1) << 26 | the digest's low bits: done << 10 | z_next (| local-row high bits) */ \
-            "v_cmp_le_u32_e64 %[amb], %[samb], %[d]\n\t"                 /* the draw is above the entry by <= 17 units of T21: exact look */ \
-            "v_cndmask_b32_e64 %[key], %[key], -1, vcc\n\t"              /* (two instructions behind the one that wrote vcc, two ahead of the DPP read) */ \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                    \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_min_u32_dpp %[key], %[key], %[key] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
-            "v_and_b32 " ZN ", %[szm], %[key]\n\t"                       /* next state (| done << 10: an event) */      \
+            "v_min_u32_dpp " KEY ", " KEY ", " KEY " row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                      \
+            "v_and_b32 " ZN ", v113, " KEY "\n\t"                        /* next state (| done << 10: an event) */      \
             "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
             "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (ahead of the store: wrong if it is this state -- an event) */ \
-            "v_add_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
-            "v_and_or_b32 %[nrd], %[c4], %[srmask], %[ringa]\n\t"                                                         \
+            "v_add_u32_sdwa %[c4], %[c4], " KEY " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
+            "v_and_or_b32 %[nrd], %[c4], v115, %[ringa]\n\t"                                                              \
             "ds_read_b32 %[kt], %[nrd]\n\t"                              /* next look's draw */                          \
             "v_xad_u32 %[e], " ZN ", " ZZ ", -1\n\t"                      /* (next ^ this) - 1 */                         \
-            "v_cmp_lt_u32_e64 %[ev], %[srmask], %[e]\n\t"                /* same state, episode end, or the all-ones key of a row without a clear accept (<= 256 states: otherwise < 0x100) */ \
-            "v_sub_co_u32_sdwa %[tt], vcc, %[li4w], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
+            "v_cmp_lt_u32_e64 %[ev], v115, %[e]\n\t"                     /* same state, episode end, or the all-ones key of a row without a clear accept */ \
+            "v_sub_co_u32_sdwa %[tt], vcc, v110, " KEY " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* slot (x4) of this lane's entry after the shift; borrow: it was consumed */ \
             "v_cndmask_b32_e64 %[d], " W ", 0, vcc\n\t"                                                                   \
             "v_bfi_b32 %[tt], 28, %[tt], " RA "\n\t"                     /* its address in this state's row */           \
             "s_or_b64 %[ev], %[ev], %[amb]\n\t"                                                                           \
             "s_cbranch_scc1 " EPI "f\n\t"                                                                                 \
             /* ---- no lane of the wavefront has an event: commit the step of all four rows ---- */                      \
             "ds_write_b32 %[tt], %[d]\n\t"                               /* the row, shifted */                          \
-            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"              /* log word: state left | candidates consumed << 26 */ \
-            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"                                                           \
-            "s_waitcnt lgkmcnt(2)\n\t"                                   /* the two reads; the two stores behind them may still be on their way (one wavefront's DS instructions execute in issue order) */
-#endif
-        /* Out of line: the only event of the look is the end of an episode in some rows (psrs.py:249-269: env.reset() pops */   \
-        /* the shuffled init queue).  The row's next initial states wait in its LDS ring; `left` says how many the loop may   */  \
-        /* take before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed with */ \
-        /* the log word marked "done", the next state of those rows is their next initial state. */
-#define ROWS_EPI(LOGOFF, EPI, BACK, OUT, ZZ, RA, W, ZN, RN, WN)                                                           \
+            "s_waitcnt lgkmcnt(1)\n\t"                                   /* the two reads */
+        /* Out of line: the look's events are episode ends (psrs.py:249-269: env.reset() pops the shuffled init queue) and / or rows  */  \
+        /* that stay in their state.  The row's next initial states wait in its LDS ring; `left` says how many the loop may take     */  \
+        /* before the C++ path has to look (episode cap, init queue empty, ring to refill).  The step is committed (its key carries  */  \
+        /* the done bit into the log word the next copy makes), the next state of the rows whose episode ended is their next initial */  \
+        /* state, and every row's entry is read again behind the row store.  DRY: where a row without a clear accept goes.          */
+#define ROWS_EPI(EPI, BACK, OUT, DRY, ZZ, RA, W, ZN, RN, WN, KEY, KEYP, LMSH)                                                 \
             EPI ":\n\t"                                                                                                    \
             "s_cmp_lg_u64 %[amb], 0\n\t"                                                                                   \
             "s_cbranch_scc1 " OUT "f\n\t"                               /* a lane needs the exact look */                  \
-            "v_cmp_eq_u32_e32 vcc, -1, %[key]\n\t"                     /* all-ones key: a row without a clear accept */   \
-            "s_cbranch_vccnz " OUT "f\n\t"                                                                                 \
+            "v_cmp_eq_u32_e32 vcc, -1, " KEY "\n\t"                     /* all-ones key: a row without a clear accept */   \
+            "s_cbranch_vccnz " DRY "f\n\t"                                                                                 \
             "v_cmp_le_u32_e32 vcc, 0x400, " ZN "\n\t"                   /* vcc: the rows whose episode ends */             \
             "v_cmp_eq_u32_e64 %[ev], 0, %[left]\n\t"                                                                       \
-            "v_and_or_b32 %[e], %[key], %[skm], " ZZ "\n\t"                                                                \
             "s_and_b64 %[ev], %[ev], vcc\n\t"                                                                              \
             "s_cbranch_scc1 " OUT "f\n\t"                               /* a row may not take another reset here */       \
             "s_mov_b64 exec, vcc\n\t"                                                                                      \
             "ds_read_b32 " ZN ", %[initp]\n\t"                          /* the next initial state */                      \
             "v_subrev_u32 %[left], 1, %[left]\n\t"                                                                         \
             "v_add_u32 %[initp], 4, %[initp]\n\t"                                                                          \
-            "v_or_b32 %[e], 0x400, %[e]\n\t"                            /* log word of an episode end */                  \
             "v_and_b32 %[initp], 0xffffff7f, %[initp]\n\t"              /* the ring of 32 is 128 bytes at a 256-byte boundary: wrap */ \
             "s_mov_b64 exec, %[live]\n\t"                                                                                  \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                 \
-            "ds_write_b32 %[logb], %[e] offset:" LOGOFF "\n\t"                                                             \
-            "s_waitcnt lgkmcnt(2)\n\t"                                                                                     \
+            "s_waitcnt lgkmcnt(1)\n\t"                                  /* (the early entry read, the draw, the initial state) */ \
             "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"                                                               \
             "ds_read_b32 " WN ", " RN "\n\t"                                                                               \
-            ROWS_EPI_WAIT                                                                                                  \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
             "s_branch " BACK "b\n\t"
         // an event the loop does not serve: nothing of copy I is committed, the row state goes where the C++ code expects it
-#define ROWS_OUT_A(OUT, I) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 2f\n\t"
-#define ROWS_OUT_B(OUT, I) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 22f\n\t"
-#define RA "%[zz]", "%[ra]", "%[w]", "%[zn]", "%[rb]", "%[w2]"
-#define RB "%[zn]", "%[rb]", "%[w2]", "%[zz]", "%[ra]", "%[w]"
+#define ROWS_OUT_A(OUT, DRY, I, DRYT) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 2f\n\t" DRY ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch " DRYT "0f\n\t"
+#define ROWS_OUT_B(OUT, DRY, I, DRYT) OUT ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch 22f\n\t" DRY ":\n\t" "s_movk_i32 %[it], " I "\n\t" "s_branch " DRYT "1f\n\t"
+#define RA "%[zz]", "%[ra]", "%[w]", "%[zn]", "%[rb]", "%[w2]", "%[key]", "%[key2]"
+#define RB "%[zn]", "%[rb]", "%[w2]", "%[zz]", "%[ra]", "%[w]", "%[key2]", "%[key]"
 #define ROWS_STEP_(...) ROWS_STEP(__VA_ARGS__)
 #define ROWS_EPI_(...) ROWS_EPI(__VA_ARGS__)
-        asm volatile(
-            "s_mov_b64 s[24:25], exec\n\t"                               // rows that have stopped sit the loop out: nothing of theirs is read or written
-            "s_mov_b64 exec, %[live]\n\t"
-            "v_mov_b32 %[zn], %[zz]\n\t"                                 // both register sets hold the row state: any copy may be the first
-            "v_mov_b32 %[rb], %[ra]\n\t"
-            "v_mov_b32 %[w2], %[w]\n\t"
-            ROWS_ENTRY_WAIT
-            "s_cmp_eq_u32 %[it], 0\n\t"
-            "s_cbranch_scc1 100f\n\t"
-            "s_getpc_b64 s[20:21]\n\t"                                   // = the address of the next instruction; the table starts 20 bytes behind it
-            "s_lshl_b32 s22, %[it], 2\n\t"
-            "s_add_u32 s22, s22, 20\n\t"
-            "s_add_u32 s20, s20, s22\n\t"
-            "s_addc_u32 s21, s21, 0\n\t"
-            "s_setpc_b64 s[20:21]\n\t"
-            "s_branch 100f\n\t" "s_branch 101f\n\t" "s_branch 102f\n\t" "s_branch 103f\n\t"
-            "s_branch 104f\n\t" "s_branch 105f\n\t" "s_branch 106f\n\t" "s_branch 107f\n\t"
-            "s_branch 108f\n\t" "s_branch 109f\n\t" "s_branch 110f\n\t" "s_branch 111f\n\t"
-            "s_branch 112f\n\t" "s_branch 113f\n\t" "s_branch 114f\n\t" "s_branch 115f\n\t"
-            ROWS_STEP_("0", "200", "100", RA)
-            ROWS_STEP_("4", "201", "101", RB)
-            ROWS_STEP_("8", "202", "102", RA)
-            ROWS_STEP_("12", "203", "103", RB)
-            ROWS_STEP_("16", "204", "104", RA)
-            ROWS_STEP_("20", "205", "105", RB)
-            ROWS_STEP_("24", "206", "106", RA)
-            ROWS_STEP_("28", "207", "107", RB)
-            ROWS_STEP_("32", "208", "108", RA)
-            ROWS_STEP_("36", "209", "109", RB)
-            ROWS_STEP_("40", "210", "110", RA)
-            ROWS_STEP_("44", "211", "111", RB)
-            ROWS_STEP_("48", "212", "112", RA)
-            ROWS_STEP_("52", "213", "113", RB)
-            ROWS_STEP_("56", "214", "114", RA)
-            ROWS_STEP_("60", "215", "115", RB)
-            "116:\n\t"
-            "s_movk_i32 %[it], 16\n\t"                                   // the tick is over; copy 15 left the row state in (zz, ra, w)
-            "s_branch 3f\n\t"
-            ROWS_EPI_("0", "200", "101", "300", RA)
-            ROWS_EPI_("4", "201", "102", "301", RB)
-            ROWS_EPI_("8", "202", "103", "302", RA)
-            ROWS_EPI_("12", "203", "104", "303", RB)
-            ROWS_EPI_("16", "204", "105", "304", RA)
-            ROWS_EPI_("20", "205", "106", "305", RB)
-            ROWS_EPI_("24", "206", "107", "306", RA)
-            ROWS_EPI_("28", "207", "108", "307", RB)
-            ROWS_EPI_("32", "208", "109", "308", RA)
-            ROWS_EPI_("36", "209", "110", "309", RB)
-            ROWS_EPI_("40", "210", "111", "310", RA)
-            ROWS_EPI_("44", "211", "112", "311", RB)
-            ROWS_EPI_("48", "212", "113", "312", RA)
-            ROWS_EPI_("52", "213", "114", "313", RB)
-            ROWS_EPI_("56", "214", "115", "314", RA)
-            ROWS_EPI_("60", "215", "116", "315", RB)
-            ROWS_OUT_A("300", "0") ROWS_OUT_B("301", "1") ROWS_OUT_A("302", "2") ROWS_OUT_B("303", "3")
-            ROWS_OUT_A("304", "4") ROWS_OUT_B("305", "5") ROWS_OUT_A("306", "6") ROWS_OUT_B("307", "7")
-            ROWS_OUT_A("308", "8") ROWS_OUT_B("309", "9") ROWS_OUT_A("310", "10") ROWS_OUT_B("311", "11")
-            ROWS_OUT_A("312", "12") ROWS_OUT_B("313", "13") ROWS_OUT_A("314", "14") ROWS_OUT_B("315", "15")
-            "22:\n\t"                                                    // event in an odd copy: its state is in (zn, rb, w2)
-            "s_waitcnt lgkmcnt(0)\n\t"                                   // (the early read of the next entry is on its way into w)
-            "v_mov_b32 %[zz], %[zn]\n\t"
-            "v_mov_b32 %[ra], %[rb]\n\t"
-            "v_mov_b32 %[w], %[w2]\n\t"
-            "2:\n\t"
-            "v_sub_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  // nothing of this iteration is committed
-            "3:\n\t"
-            "s_mov_b64 exec, s[24:25]\n\t"
-            "s_waitcnt lgkmcnt(0)"                                       // no read of this loop outlives it
-            : [w] "+v"(w), [kt] "+v"(kt), [c4] "+v"(c4), [ra] "+v"(ra), [zz] "+v"(zz), [initp] "+v"(initp), [left] "+v"(left),
-              [key] "=&v"(key), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd), [e] "=&v"(e), [zn] "=&v"(zn), [rb] "=&v"(rb), [w2] "=&v"(w2),
-              [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)
-            : [lif] "v"(lifield), [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [li4w] "v"(li4w), [logb] "v"(log_a),
-              [spay] "s"(F.paymask), [szm] "s"(F.zmask), [samb] "s"(F.amb), [srmask] "s"(ROWS_RING * 4u - 4u), [skm] "s"(F.emask), [live] "s"(live)
-            : "vcc", "scc", "memory", "s20", "s21", "s22", "s24", "s25");
+        // The dry-row handler (stream format A).  Label 51: the event came from an odd copy, its row state goes to (zz, ra, w, key)
+        // first; label 50: the handler.  Temporaries: hv = %[nrd] (entries the window held), p = %[e] (queue position behind the
+        // window), dg = %[w2] (sixteen candidates, lane = position), v[120:121] = the state's segment, v122 = compare, v123 = land
+        // address / scratch, v[124:125] = address, v126, v127, v117..v119 scratch; s[30:31] = the rows without a clear accept,
+        // s[32:33] = lanes.  Nothing of the iteration is committed before the last test has passed; what it leaves for the entry
+        // code: the state and the reads of the next look, and in `key` the log word of this step (the first copy after an entry
+        // writes "the step before it" from key).
+#ifdef ROWS_DRY_BISECT1  /* (debug build: every dry event leaves for the C++ path after the handler's tests) */
+#define ROWS_DRY_T1 "s_branch 52f\n\t"
+#else
+#define ROWS_DRY_T1
+#endif
+#define ROWS_DRY_HANDLER                                                                                                     \
+            "51:\n\t"                                                                                                     \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
+            "v_mov_b32 %[ra], %[rb]\n\t"                                                                                  \
+            "v_mov_b32 %[w], %[w2]\n\t"                                                                                   \
+            "v_mov_b32 %[key], %[key2]\n\t"                                                                               \
+            "50:\n\t"                                                                                                     \
+            "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the early read of the next entry is on its way into w2) */ \
+            "v_cmp_eq_u32_e64 s[30:31], -1, %[key]\n\t"                  /* the rows without a clear accept */           \
+            /* may every row that needs one take an initial state?  (a dry row's step may end an episode: asked of all of them) */ \
+            "v_and_b32 v117, 0x400, %[key]\n\t"                                                                           \
+            "v_cmp_ne_u32_e32 vcc, 0, v117\n\t"                                                                           \
+            "v_cmp_eq_u32_e64 s[32:33], 0, %[left]\n\t"                                                                   \
+            "s_and_b64 s[32:33], s[32:33], vcc\n\t"                      /* (the all-ones key carries the done bit: covers the dry rows) */ \
+            "s_cbranch_scc1 2f\n\t"                                                                                       \
+            /* entries the window held: lanes 0..7 (8..15 repeat them) */                                                \
+            "v_cmp_ne_u32_e32 vcc, 0, %[w]\n\t"                                                                           \
+            "v_lshl_add_u32 v123, %[zz], 2, %[landb]\n\t"                /* &land[state] */                              \
+            "v_lshl_add_u32 v126, %[zz], 2, %[sega]\n\t"                 /* &seg_off[state] */                           \
+            "v_cndmask_b32_e64 %[nrd], 0, 1, vcc\n\t"                                                                     \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+            "ds_read_b32 %[e], v123\n\t"                                                                                  \
+            "ds_read2_b32 v[120:121], v126 offset1:1\n\t"                                                                 \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                     \
+            "v_lshrrev_b32 v118, 2, %[li4]\n\t"                          /* lane of the row, 0..15 */                    \
+            "v_add_u32 v119, 4, %[li4]\n\t"                                                                               \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                         \
+            "v_lshlrev_b32 v119, 24, v119\n\t"                           /* (lane + 1) << 26 */                          \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_sub_u32 v122, v121, v120\n\t"                             /* rows of the state */                         \
+            "v_sub_u32 v122, v122, %[e]\n\t"                             /* ... still queued behind the window */        \
+            "v_cmp_gt_u32_e32 vcc, 16, v122\n\t"                         /* fewer than sixteen: the C++ path */          \
+            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
+            "s_cbranch_vccnz 2f\n\t"                                                                                      \
+            /* draw counter of the dry rows behind the entries held: c4 - 255 (the all-ones key was added) + 4 hv, as a 16-lane slot */ \
+            "v_add_u32 v127, 0xffffff01, %[c4]\n\t"                                                                       \
+            "v_lshl_add_u32 v127, %[nrd], 2, v127\n\t"                                                                    \
+            "v_sub_u32 v127, v127, v110\n\t"                             /* 4 x draws consumed */                        \
+            "s_sub_u32 s32, 17, %[it]\n\t"                               /* this event's sixteen draws, and eight for every look left in the tick (the loop */ \
+            "s_lshl_b32 s32, s32, 5\n\t"                                 /* itself never checks: a tick's worth is in the ring when it starts): 4 x (16 + 8 (15 - it)) */ \
+            "v_add_u32 v126, s32, v127\n\t"                                                                               \
+            "v_cmp_gt_u32_e32 vcc, v126, %[gen4]\n\t"                    /* ... are not known to be in the ring */     \
+            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
+            "s_cbranch_vccnz 2f\n\t"                                                                                      \
+            "v_add_u32 v127, v127, %[li4]\n\t"                                                                            \
+            "v_and_or_b32 v126, v127, v115, %[ringa]\n\t"                                                                 \
+            "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* grouped position of this lane's candidate */ \
+            "v_mov_b32 v125, 0\n\t"                                                                                       \
+            "v_lshl_add_u64 v[124:125], v[124:125], 2, %[dbase]\n\t"                                                      \
+            /* Candidates up to the end of the 64-byte sector the queue's head lies in: the window's last top-up came out of that */ \
+            /* sector, so it is in L2 / the Infinity Cache (~300 cycles); the one behind it is an HBM round trip (~2500: measured).*/ \
+            "v_lshrrev_b32 v121, 2, v124\n\t"                                                                             \
+            "v_sub_u32 v121, v121, v118\n\t"                                                                              \
+            "v_and_b32 v121, 15, v121\n\t"                                                                                \
+            "v_sub_u32 v121, 16, v121\n\t"                             /* candidates in the sector, 1..16 (the same in every lane of the row) */ \
+            "v_cmp_lt_u32_e32 vcc, v118, v121\n\t"                                                                        \
+            "s_mov_b64 exec, s[30:31]\n\t"                                                                                \
+            "v_mov_b32 %[zn], -1\n\t"                                  /* (a lane without a candidate accepts nothing) */ \
+            "s_and_b64 exec, exec, vcc\n\t"                                                                               \
+            "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
+            "ds_read_b32 v117, v126\n\t"                                 /* draw c + hv + lane */                        \
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                           \
+            "v_cmp_lt_u32_e32 vcc, 0x8000, %[w2]\n\t"                    /* the window's bias (rows_bias) */             \
+            "v_add_u32 v122, 0xffff8000, %[w2]\n\t"                                                                       \
+            "v_mov_b32 v125, 0x200\n\t"                                  /* ROWS_NEVER (a literal and vcc do not share the constant bus) */ \
+            "s_nop 0\n\t"                                                                                                 \
+            "v_cndmask_b32_e32 v122, v125, v122, vcc\n\t"                                                                 \
+            "v_sub_co_u32 v126, vcc, v122, v117\n\t"                     /* borrow: not a clear accept */                \
+            "v_and_or_b32 %[zn], %[w2], v112, v119\n\t"                                                                   \
+            "v_cmp_le_u32_e64 s[32:33], v114, v126\n\t"                  /* a lane near a tie: the C++ path */           \
+            "v_cndmask_b32_e64 %[zn], %[zn], -1, vcc\n\t"                                                                 \
+            "s_mov_b64 exec, s[30:31]\n\t"                             /* (all sixteen lanes of the dry rows again) */  \
+            "s_cmp_lg_u64 s[32:33], 0\n\t"                                                                                \
+            "s_cbranch_scc1 52f\n\t"                                                                                      \
+            "v_min_u32_dpp %[zn], %[zn], %[zn] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                        \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[zn], %[zn], %[zn] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                        \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[zn], %[zn], %[zn] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                            \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_min_u32_dpp %[zn], %[zn], %[zn] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                                  \
+            "s_nop 0\n\t"                                                                                                 \
+            "v_cmp_eq_u32_e32 vcc, -1, %[zn]\n\t"                        /* sixteen rejections in a row: the C++ path */ \
+            "s_cbranch_vccnz 52f\n\t"                                                                                     \
+            ROWS_DRY_T1                                                                                                    \
+            /* ---- every test has passed: commit.  The dry rows first (exec): draw counter, log word, land ---- */       \
+            "v_add_u32 %[c4], 0xffffff01, %[c4]\n\t"                                                                      \
+            "v_lshl_add_u32 %[c4], %[nrd], 2, %[c4]\n\t"                                                                  \
+            "v_add_u32_sdwa %[c4], %[c4], %[zn] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"   \
+            "v_lshlrev_b32 v127, 2, %[nrd]\n\t"                                                                           \
+            "v_add_u32_sdwa v127, v127, %[zn] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"     /* 4 x candidates the step consumed */ \
+            "v_lshlrev_b32 v127, 9, v127\n\t"                                                                             \
+            "v_and_b32 v126, 0x400, %[zn]\n\t"                                                                            \
+            "v_or3_b32 v127, v127, v126, %[zz]\n\t"                                                                       \
+            "v_or_b32 v127, 0x80000000, v127\n\t"                        /* rows_log_word(state left, done, candidates) */ \
+            "v_lshrrev_b32 v125, 26, %[zn]\n\t"                          /* k1: the accepted candidate is the k1-th of the sixteen */ \
+            "v_sub_u32 v126, v121, v125\n\t"                                                                              \
+            "v_min_u32 v126, 8, v126\n\t"                                /* candidates behind it (of the sector's) that become the window */ \
+            "v_add3_u32 v126, %[e], v125, v126\n\t"                                                                       \
+            "ds_write_b32 v123, v126\n\t"                                /* land = the position behind the window */     \
+            "v_add_u32 %[ndry], 1, %[ndry]\n\t"                                                                           \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            "ds_write_b32 %[tt], %[d]\n\t"                               /* the rows with a clear accept: shifted; the dry rows: emptied (every lane's slot: the all-ones key) */ \
+            "s_mov_b64 exec, s[30:31]\n\t"                                                                                \
+            "v_sub_u32_sdwa v126, %[li4], %[zn] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"   /* 4 x (lane - k1): this lane's slot in the new window */ \
+            "v_sub_u32 v124, %[ra], v110\n\t"                                                                             \
+            "v_cmp_gt_u32_e32 vcc, 32, v126\n\t"                                                                          \
+            "v_add_u32 v124, v124, v126\n\t"                                                                              \
+            "v_cmp_lt_u32_e64 s[32:33], v118, v121\n\t"                  /* (only the sector's candidates) */            \
+            "s_and_b64 exec, exec, vcc\n\t"                                                                               \
+            "s_and_b64 exec, exec, s[32:33]\n\t"                                                                          \
+            "ds_write_b32 v124, v122\n\t"                                                                                 \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            /* ---- all rows: the key that counts, the log word, the next state ---- */                                  \
+            "v_and_or_b32 v126, %[key], v116, %[zz]\n\t"                 /* log word of a row with a clear accept */     \
+            "v_cndmask_b32_e64 %[zn], %[key], %[zn], s[30:31]\n\t"                                                        \
+            "v_cndmask_b32_e64 %[key], v126, v127, s[30:31]\n\t"         /* -> last_log */                               \
+            "v_and_b32 %[zz], v113, %[zn]\n\t"                                                                            \
+            "v_cmp_le_u32_e32 vcc, 0x400, %[zz]\n\t"                     /* the rows whose episode ends */               \
+            "s_mov_b64 exec, vcc\n\t"                                                                                     \
+            "ds_read_b32 %[zz], %[initp]\n\t"                                                                             \
+            "v_subrev_u32 %[left], 1, %[left]\n\t"                                                                        \
+            "v_add_u32 %[initp], 4, %[initp]\n\t"                                                                         \
+            "v_and_b32 %[initp], 0xffffff7f, %[initp]\n\t"                                                                \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            "v_and_or_b32 %[nrd], %[c4], v115, %[ringa]\n\t"                                                              \
+            "ds_read_b32 %[kt], %[nrd]\n\t"                                                                               \
+            "s_waitcnt lgkmcnt(1)\n\t"                                                                                    \
+            "v_lshl_add_u32 %[ra], %[zz], 5, %[winrd]\n\t"                                                                \
+            "ds_read_b32 %[w], %[ra]\n\t"                                /* behind every store of the step */            \
+            "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
+            "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the entry code copies w and kt into the second register set) */ \
+            "s_cmp_lt_u32 %[it], 16\n\t"                                                                                  \
+            "s_cbranch_scc1 40b\n\t"                                     /* enter the loop again at the next copy */     \
+            "s_lshl_b64 s[22:23], s[26:27], 15\n\t"                      /* it was the tick's last step: its log word */ \
+            "s_nop 0\n\t"                                                                                                 \
+            "v_cndmask_b32_e64 %[elog], %[elog], %[key], s[22:23]\n\t"                                                    \
+            "s_branch 3f\n\t"                                                                                             \
+            "52:\n\t"                                                                                                     \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            "s_branch 2f\n\t"
+#define ROWS_FAST_ASM(SPAY, SZM, SAMB, SKM, DRYT, HANDLER)                                                                    \
+        asm volatile(                                                                                                    \
+            "s_mov_b64 s[24:25], exec\n\t"                               /* rows that have stopped sit the loop out: nothing of theirs is read or written */ \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            "s_mov_b32 s26, 0x10001\n\t"                                 /* s[26:27]: lane 0 of every row */              \
+            "s_mov_b32 s27, 0x10001\n\t"                                                                                  \
+            "v_and_b32 v110, 28, %[li4]\n\t"                                                                              \
+            "v_mov_b32 v112, " SPAY "\n\t"                                                                                \
+            "v_mov_b32 v113, " SZM "\n\t"                                                                                 \
+            "v_add_u32 v111, 4, v110\n\t"                                                                                 \
+            "v_mov_b32 v114, " SAMB "\n\t"                                                                                \
+            "v_mov_b32 v115, 0x3fc\n\t"                                                                                   \
+            "v_lshlrev_b32 v111, 24, v111\n\t"                                                                            \
+            "v_mov_b32 v116, " SKM "\n\t"                                                                                 \
+            "40:\n\t"                                                                                                     \
+            "v_mov_b32 %[zn], %[zz]\n\t"                                 /* both register sets hold the row state: any copy may be the first */ \
+            "v_mov_b32 %[rb], %[ra]\n\t"                                                                                  \
+            "v_mov_b32 %[w2], %[w]\n\t"                                                                                   \
+            "v_mov_b32 %[key2], %[key]\n\t"                              /* (key arrives holding last_log: the first copy rebuilds that word, whichever its parity) */ \
+            "v_bfi_b32 %[e], v116, 0, %[key]\n\t"                        /* last_log outside the key's part of a log word: what the first copy takes for "the state left" */ \
+            "s_bitcmp1_b32 %[it], 0\n\t"                                                                                  \
+            "s_cbranch_scc1 31f\n\t"                                                                                      \
+            "v_mov_b32 %[zn], %[e]\n\t"                                  /* an even copy comes first: it reads the previous step's state from zn */ \
+            "s_branch 32f\n\t"                                                                                            \
+            "31:\n\t"                                                                                                     \
+            "v_mov_b32 %[zz], %[e]\n\t"                                  /* an odd copy comes first (its own state is in zn, rb, w2) */ \
+            "32:\n\t"                                                                                                     \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "s_cmp_eq_u32 %[it], 0\n\t"                                                                                   \
+            "s_cbranch_scc1 100f\n\t"                                                                                     \
+            "s_getpc_b64 s[20:21]\n\t"                                   /* = the address of the next instruction; the table starts 20 bytes behind it */ \
+            "s_lshl_b32 s22, %[it], 2\n\t"                                                                                \
+            "s_add_u32 s22, s22, 20\n\t"                                                                                  \
+            "s_add_u32 s20, s20, s22\n\t"                                                                                 \
+            "s_addc_u32 s21, s21, 0\n\t"                                                                                  \
+            "s_setpc_b64 s[20:21]\n\t"                                                                                    \
+            "s_branch 100f\n\t" "s_branch 101f\n\t" "s_branch 102f\n\t" "s_branch 103f\n\t"                              \
+            "s_branch 104f\n\t" "s_branch 105f\n\t" "s_branch 106f\n\t" "s_branch 107f\n\t"                              \
+            "s_branch 108f\n\t" "s_branch 109f\n\t" "s_branch 110f\n\t" "s_branch 111f\n\t"                              \
+            "s_branch 112f\n\t" "s_branch 113f\n\t" "s_branch 114f\n\t" "s_branch 115f\n\t"                              \
+            ROWS_STEP_("200", "100", RA, "63")                                                                            \
+            ROWS_STEP_("201", "101", RB, "0")                                                                             \
+            ROWS_STEP_("202", "102", RA, "1")                                                                             \
+            ROWS_STEP_("203", "103", RB, "2")                                                                             \
+            ROWS_STEP_("204", "104", RA, "3")                                                                             \
+            ROWS_STEP_("205", "105", RB, "4")                                                                             \
+            ROWS_STEP_("206", "106", RA, "5")                                                                             \
+            ROWS_STEP_("207", "107", RB, "6")                                                                             \
+            ROWS_STEP_("208", "108", RA, "7")                                                                             \
+            ROWS_STEP_("209", "109", RB, "8")                                                                             \
+            ROWS_STEP_("210", "110", RA, "9")                                                                             \
+            ROWS_STEP_("211", "111", RB, "10")                                                                            \
+            ROWS_STEP_("212", "112", RA, "11")                                                                            \
+            ROWS_STEP_("213", "113", RB, "12")                                                                            \
+            ROWS_STEP_("214", "114", RA, "13")                                                                            \
+            ROWS_STEP_("215", "115", RB, "14")                                                                            \
+            "116:\n\t"                                                                                                    \
+            "v_and_or_b32 %[e], %[key2], v116, %[zn]\n\t"                /* the tick is over: the last step's log word; copy 15 left the row state in (zz, ra, w) */ \
+            "s_lshl_b64 s[22:23], s[26:27], 15\n\t"                                                                       \
+            "s_movk_i32 %[it], 16\n\t"                                                                                    \
+            "v_cndmask_b32_e64 %[elog], %[elog], %[e], s[22:23]\n\t"                                                      \
+            "s_branch 3f\n\t"                                                                                             \
+            ROWS_EPI_("200", "101", "300", "400", RA, "0")                                                                \
+            ROWS_EPI_("201", "102", "301", "401", RB, "0")                                                                \
+            ROWS_EPI_("202", "103", "302", "402", RA, "0")                                                                \
+            ROWS_EPI_("203", "104", "303", "403", RB, "0")                                                                \
+            ROWS_EPI_("204", "105", "304", "404", RA, "0")                                                                \
+            ROWS_EPI_("205", "106", "305", "405", RB, "0")                                                                \
+            ROWS_EPI_("206", "107", "306", "406", RA, "0")                                                                \
+            ROWS_EPI_("207", "108", "307", "407", RB, "0")                                                                \
+            ROWS_EPI_("208", "109", "308", "408", RA, "0")                                                                \
+            ROWS_EPI_("209", "110", "309", "409", RB, "0")                                                                \
+            ROWS_EPI_("210", "111", "310", "410", RA, "0")                                                                \
+            ROWS_EPI_("211", "112", "311", "411", RB, "0")                                                                \
+            ROWS_EPI_("212", "113", "312", "412", RA, "0")                                                                \
+            ROWS_EPI_("213", "114", "313", "413", RB, "0")                                                                \
+            ROWS_EPI_("214", "115", "314", "414", RA, "0")                                                                \
+            ROWS_EPI_("215", "116", "315", "415", RB, "0")                                                                \
+            ROWS_OUT_A("300", "400", "0", DRYT) ROWS_OUT_B("301", "401", "1", DRYT) ROWS_OUT_A("302", "402", "2", DRYT) ROWS_OUT_B("303", "403", "3", DRYT)  \
+            ROWS_OUT_A("304", "404", "4", DRYT) ROWS_OUT_B("305", "405", "5", DRYT) ROWS_OUT_A("306", "406", "6", DRYT) ROWS_OUT_B("307", "407", "7", DRYT)  \
+            ROWS_OUT_A("308", "408", "8", DRYT) ROWS_OUT_B("309", "409", "9", DRYT) ROWS_OUT_A("310", "410", "10", DRYT) ROWS_OUT_B("311", "411", "11", DRYT) \
+            ROWS_OUT_A("312", "412", "12", DRYT) ROWS_OUT_B("313", "413", "13", DRYT) ROWS_OUT_A("314", "414", "14", DRYT) ROWS_OUT_B("315", "415", "15", DRYT) \
+            HANDLER                                                                                                       \
+            "60:\n\t"                                                    /* (stream format B: a row without a clear accept leaves for the C++ path) */ \
+            "s_branch 2f\n\t"                                                                                             \
+            "61:\n\t"                                                                                                     \
+            "22:\n\t"                                                    /* event in an odd copy: its state is in (zn, rb, w2), its key in key2 */ \
+            "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the early read of the next entry is on its way into w) */ \
+            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
+            "v_mov_b32 %[ra], %[rb]\n\t"                                                                                  \
+            "v_mov_b32 %[w], %[w2]\n\t"                                                                                   \
+            "v_mov_b32 %[key], %[key2]\n\t"                                                                               \
+            "2:\n\t"                                                                                                      \
+            "v_sub_u32_sdwa %[c4], %[c4], %[key] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  /* nothing of this iteration is committed */ \
+            "3:\n\t"                                                                                                      \
+            "s_mov_b64 exec, s[24:25]\n\t"                                                                                \
+            "s_waitcnt lgkmcnt(0)"                                       /* no read of this loop outlives it */          \
+            : [w] "+v"(w), [kt] "+v"(kt), [c4] "+v"(c4), [ra] "+v"(ra), [zz] "+v"(zz), [initp] "+v"(initp), [left] "+v"(left), [key] "+v"(key),         \
+              [elog] "+v"(elog), [ndry] "+v"(n_dry), [key2] "=&v"(key2), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd), [e] "=&v"(e), [zn] "=&v"(zn),  \
+              [rb] "=&v"(rb), [w2] "=&v"(w2), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)                                                           \
+            : [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [li4] "v"(li4), [landb] "v"(land_a), [gen4] "v"(gen4), [dbase] "v"(dbase), [sega] "s"(seg_a),  \
+              [live] "s"(live)                                                                                                                           \
+            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s30", "s31", "s32", "s33", "v110", "v111", "v112",        \
+              "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+        static_assert(rows_format(OFFSIM_STREAMS_A).paymask == 0x7ffu && rows_format(OFFSIM_STREAMS_A).zmask == 0x7ffu &&
+                      rows_format(OFFSIM_STREAMS_A).amb == 0xffff7800u && (rows_format(OFFSIM_STREAMS_A).emask | 0x400u) == 0x3c000400u &&
+                      rows_format(OFFSIM_STREAMS_A).bias == 0x8000u && rows_format(OFFSIM_STREAMS_A).smask == 0x3ffu, "the literals of the format-A loop");
+        static_assert(rows_format(OFFSIM_STREAMS_B).paymask == 0xffffu && rows_format(OFFSIM_STREAMS_B).zmask == 0x4ffu &&
+                      rows_format(OFFSIM_STREAMS_B).amb == 0xfffd0000u && (rows_format(OFFSIM_STREAMS_B).emask | 0x400u) == 0x3c00ff00u, "the literals of the format-B loop");
+        if constexpr (fmt_b) {
+            ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
+        } else {
+#ifdef ROWS_NO_DRY_ASM  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
+            ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "6", "");
+#else
+            ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER);
+#endif
+        }
+#undef ROWS_FAST_ASM
+#undef ROWS_DRY_HANDLER
 #undef ROWS_STEP
 #undef ROWS_EPI
-#undef ROWS_EPI_WAIT
-#undef ROWS_ENTRY_WAIT
 #undef ROWS_OUT_A
 #undef ROWS_OUT_B
 #undef ROWS_STEP_
@@ -1185,10 +1382,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     };
     // the iteration the loop was left in, from what it handed over (no second look, no re-read of the window)
     auto resume_step = [&](uint32_t it) __attribute__((always_inline)) {
+        PS_T1();
         const uint32_t key = ex_key;
         const bool amb = ((uint32_t)(ex_amb >> (rw * 16u)) & 0xffffu) != 0u;
         if (key != 0xffffffffu && !amb) {  // clear accept: the stores the loop had prepared, then the episode end if that was the event
-            LV32(log_a + it * 4u) = (key & (F.emask | 0x400u)) | z;
+            log_step(it, (key & (F.emask | 0x400u)) | z);
             LV32(ex_slot) = ex_d;
             c += (key >> ROWS_LIF) & 15u;
             z = key & F.smask;
@@ -1196,10 +1394,15 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 ep++;
                 do_reset(it + 1u);
             }
+            PS(3);
         } else {
             exact_step(it, amb);
+            PS(8);
         }
+#ifndef ROWS_T_NODRAWCHECK  /* (timing experiment only) */
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);
+#endif
+        PS(9);
     };
 
     if (!dead) need_draws(136u, 0u);  // (HELPER: the helper wavefront has filled the ring)

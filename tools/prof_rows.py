@@ -25,6 +25,8 @@ ph = o["ep_g"].cpu().numpy()[::16].mean(axis=0)
 names = ["batch reads + flag", "land reads + hand-off", "landing", "-", "-", "-", "-", "counters, init prefetch, draws check"]
 print(f"chain wavefront: {ph[10] / it:.1f} cycles per iteration in all, clock {ph[10] / ph[11] * 0.1:.3f} GHz; slowest / mean wavefront {o['ep_g'].cpu().numpy()[::16, 10].max() / ph[10]:.4f}")
 print("chain tick phases (cycles per tick):", {n: int(v / (it / 16)) for n, v in zip(names, ph[:8]) if n != "-"})
+sn = {3: "rows with a clear accept commit", 4: "held + land read", 5: "segment, draws check, address", 6: "candidate load returns", 8: "look, commit, reset", 9: "draws check"}
+print("chain slow iteration phases (cycles per slow iteration; stamps inside divergent code count once per wavefront):", {v: int(ph[k] / max(nslow, 1)) for k, v in sn.items()})
 hn = {8: "poll (idle)", 9: "log read + requests", 3: "slot reads", 4: "R3 sums", 5: "R2 rewards", 6: "R1 loc/discount", 10: "draws"}
 print("helper phases (cycles per tick):", {v: int(ph[12 + k] / (it / 16)) for k, v in hn.items()})
 # spread between workgroups (one sampled wavefront each): the kernel ends with its slowest one
