@@ -1504,8 +1504,8 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     // four rollouts per wavefront; as many wavefronts per workgroup (<= 4) as the CU's 160 KiB of LDS hold regions for
     const uint32_t region = rows_region_bytes((uint32_t)t->n_slots);
     const uint32_t seg_bytes = (((uint32_t)t->n_slots + 1u) * 4u + 1023u) & ~1023u;
-    int waves = (int)((160u * 1024u - 1024u - seg_bytes) / (4u * region + ROWS_DMA_BYTES));
-    waves = waves > 4 ? 4 : waves;
+    int waves = 4;  // (the DMA areas of the workgroup are rounded up together: rows_dma_total)
+    while (waves >= 1 && 1024u + seg_bytes + rows_dma_total((uint32_t)waves) + (uint32_t)waves * 4u * region > 160u * 1024u) waves--;
     if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
 #ifdef ROWS_EXPERIMENT_ISOLATE  // measurement build: two chain wavefronts + two helpers per CU (a workgroup that takes the CU's LDS alone), one wavefront per SIMD
     waves = waves > 2 ? 2 : waves;
@@ -1514,7 +1514,7 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
 #ifdef ROWS_EXPERIMENT_ISOLATE
     const size_t lds = 100 * 1024;
 #else
-    const size_t lds = 1024 + seg_bytes + (size_t)waves * ROWS_DMA_BYTES + (size_t)rpb * region;
+    const size_t lds = 1024 + seg_bytes + (size_t)rows_dma_total((uint32_t)waves) + (size_t)rpb * region;
 #endif
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)

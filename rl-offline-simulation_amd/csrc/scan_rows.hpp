@@ -92,6 +92,8 @@ __device__ __forceinline__ uint32_t rows_held(scan_u32x4 h0, scan_u32x4 h1) {
     return (h0.x != 0u) + (h0.y != 0u) + (h0.z != 0u) + (h0.w != 0u) + (h1.x != 0u) + (h1.y != 0u) + (h1.z != 0u) + (h1.w != 0u);
 }
 
+// the DMA areas of a workgroup's wavefronts, rounded so that the rollout regions behind them stay 1024-byte aligned (the draw ring's address is formed with an OR)
+__host__ __device__ constexpr uint32_t rows_dma_total(uint32_t n_chain) { return (n_chain * 7680u + 1023u) & ~1023u; }
 __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { return (RO_WIN + n_slots * 41u + 1023u) & ~1023u; }  // 8 KiB up to 164 states
 
 // Per-wavefront landing area of the tick's global loads.  They are issued as LDS-DMA (global_load_lds_dword: no VGPR
@@ -99,14 +101,28 @@ __host__ __device__ constexpr uint32_t rows_region_bytes(uint32_t n_slots) { ret
 // it would have to wait for at the loop back-edge (a whole HBM round trip per tick, 46 % of the kernel when measured) nor
 // orders later LDS reads behind them; the next tick opens with s_waitcnt vmcnt(0) -- long satisfied -- and reads the slots.
 // (the two request areas hold FOUR dwords per lane each, lane l's at base + 16 l: one global_load_lds_dwordx4 fills an area)
-enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */, DS_LOC = 8,
-       DS_GP = 9 /* four slots: the discount factor of every lane's step (and the table entry behind it) */, DS_RLO = 13, DS_RHI,
-       DS_PROD /* two slots: 16 products per row */, DS_RQD = 17 /* the request each lane made: position | entries << 28 */,
-       DS_RQS = 18 /* ... and its state */, DS_SLOTS = 19 };
+enum { DS_RQA = 0 /* four slots: digests 0..3 of every lane's request */, DS_RQB = 4 /* four slots: digests 4..7 */,
+       DS_RQD = 8 /* the request each lane made: position | entries << 28 */, DS_RQS = 9 /* ... and its state */,
+       DS_RQ_SET = 10 /* slots from one set of request areas to the other (ROWS_LAND_LAG 2): the second set is A, B, D, S again */,
+       DS_LOC = 20, DS_GP = 21 /* four slots: the discount factor of every lane's step (and the table entry behind it) */, DS_RLO = 25, DS_RHI,
+       DS_PROD /* two slots: 16 products per row */, DS_SLOTS = 29 };
+// byte offsets of the four request areas of set 0 / 1 inside a wavefront's DMA area
+struct RowsRq { uint32_t a, b, d, s; };
+__device__ __forceinline__ RowsRq rows_rq(bool second) {
+    const uint32_t o = second ? DS_RQ_SET * 256u : 0u;
+    return RowsRq{o + DS_RQA * 256u, o + DS_RQB * 256u, o + DS_RQD * 256u, o + DS_RQS * 256u};
+}
+// Ticks between a request round and the landing of what it asked for.  1 (rounds 2 and 3): the requests of tick t's steps land at the
+// end of tick t + 1 -- one tick period minus the helper's ~1000 cycles, ~2.5 us at the round-4 loop, which 8 % of the loads on
+// the XCDs with the longer memory latency no longer make (a top-up that is late is a top-up lost: 50 % more dry windows there, and the
+// kernel ends with its slowest workgroup).  2: two sets of request areas used in turn, a round lands two ticks later (~5.4 us).
+#ifndef ROWS_LAND_LAG
+#define ROWS_LAND_LAG 2
+#endif
 #ifndef ROWS_RQ_MAX
 #define ROWS_RQ_MAX 8u  // entries a top-up asks for at most (4: the second request area stays unused)
 #endif
-#define ROWS_DMA_BYTES 5120u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
+#define ROWS_DMA_BYTES 7680u  // per wavefront: DS_SLOTS x 256 B, rounded to a multiple of 1024 (the rollout regions behind it stay 1024-byte aligned:
                               // the draw ring's address is formed with an OR)
 
 // A window entry is never ROWS_EMPTY (the entries a window holds are counted: that is the chain's only cursor): a digest at or
@@ -143,6 +159,9 @@ __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst
         : "memory");
 }
 
+#ifndef ROWS_RQ_CACHE
+#define ROWS_RQ_CACHE ""  // cache policy of the digest requests (A/B builds: " nt", " sc1", ...)
+#endif
 // four consecutive dwords per lane: lane l's land at lds_dst_uniform + 16 l
 __device__ __forceinline__ void lds_dma_x4(const void *gptr, uint32_t lds_dst_uniform) {
     uint32_t keep;
@@ -150,7 +169,7 @@ __device__ __forceinline__ void lds_dma_x4(const void *gptr, uint32_t lds_dst_un
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off" ROWS_RQ_CACHE "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gptr), "s"(lds_dst_uniform)
@@ -215,7 +234,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t rid = wave * 4u + rw;
     const int64_t r = (int64_t)blockIdx.x * rpb + rid;
     const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this pair's DMA slots
-    const uint32_t rbase = seg_a + seg_bytes + n_chain * ROWS_DMA_BYTES + rid * region_bytes;
+    const uint32_t rbase = seg_a + seg_bytes + rows_dma_total(n_chain) + rid * region_bytes;
     auto dma_slot = [&](uint32_t slot) __attribute__((always_inline)) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };
 #define ROWS_READ_A() LV128(dma_a + DS_RQA * 256u + lane * 16u)
 
@@ -226,6 +245,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
     if (HELPER && !is_helper && li < 8u) LV32(sync_a + li4) = 0u;
+    if (!is_helper) {  // no request has been made yet (the dry-row path of the loop looks at the descriptors of both sets)
+        LV32(dma_a + DS_RQD * 256u + lane * 4u) = 0u;
+        LV32(dma_a + (DS_RQ_SET + DS_RQD) * 256u + lane * 4u) = 0u;
+    }
 
     // Lanes 8..15 of a row are exact duplicates of lanes 0..7 inside the chain (same window entry, same draw, same key, same
     // stores): the row minimum then needs only the three DPP steps that stay inside eight lanes, and nothing is predicated.
@@ -671,23 +694,47 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // step was logged), as one or two 16-byte LDS-DMA loads into this pair's request areas.  Returns what it asked for
     // (0 = nothing).  (The loads fetch whole groups of four; a request that would read beyond the table's last row is left to
     // the exact path.)
-    auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n) __attribute__((always_inline)) {
+    // (rq: the set of request areas this round uses; rq_prev / odd: with two sets in turn (ROWS_LAND_LAG 2) the set of the round before,
+    // whose requests have not landed yet, and the parity of this round)
+    auto request = [&](bool mine, uint32_t s_i, uint32_t &q_s, uint32_t &q_p, uint32_t &q_n, const RowsRq rq, const RowsRq rq_prev, bool odd,
+                       bool two_sets) __attribute__((always_inline)) {
         q_n = 0;
         const uint32_t sa = mine ? s_i : 0u;  // (a lane without a step looks at state 0 and asks for nothing)
-        if (mine) LV8(claim_a + s_i) = (uint8_t)li;
-        // one batch of reads, one wait: who holds the state's claim, the window as it stands, its end, the segment
-        const uint32_t cl = LV8(claim_a + sa);
+        // The state's claim byte: the lane that tops the state up in this round.  With two sets the byte holds a lane per round parity
+        // (low nibble: even rounds), so that this round finds the request the round BEFORE made for the state -- it lands a tick from
+        // now, and a second request aimed at the same window end would be dropped when it lands in turn (9 % of all top-ups, measured).
+        uint32_t cl_prev = 0;
+        if (two_sets) {
+            const uint32_t old = LV8(claim_a + sa);
+            cl_prev = odd ? (old & 15u) : (old >> 4);
+            if (mine) LV8(claim_a + s_i) = (uint8_t)(odd ? ((old & 15u) | (li << 4)) : ((old & 0xf0u) | li));
+        } else if (mine) {
+            LV8(claim_a + s_i) = (uint8_t)li;
+        }
+        // one batch of reads, one wait: who holds the state's claim, the window as it stands, its end, the segment (and what the lane
+        // that held the claim in the round before asked for)
+        uint32_t cl = LV8(claim_a + sa);
         const scan_u32x4 h0 = LV128(win_a + sa * 32u), h1 = LV128(win_a + sa * 32u + 16u);
-        const uint32_t ld = LV32(land_a + sa * 4u), beg = seg_at(sa), len = seg_at(sa + 1u) - beg;
-        const uint32_t room = ROWS_W - rows_held(h0, h1), left = len - ld;
+        uint32_t ld = LV32(land_a + sa * 4u);
+        const uint32_t beg = seg_at(sa), len = seg_at(sa + 1u) - beg;
+        uint32_t pend = 0;
+        if (two_sets) {
+            cl = odd ? (cl >> 4) : (cl & 15u);
+            const uint32_t pd = LV32(dma_a + rq_prev.d + (rw * 16u + cl_prev) * 4u), ps = LV32(dma_a + rq_prev.s + (rw * 16u + cl_prev) * 4u);
+            pend = (ps == sa && (pd & 0xfffffffu) == ld) ? pd >> 28 : 0u;  // entries on their way to this window's end as it stands
+        }
+        const uint32_t held = rows_held(h0, h1) + pend;
+        const uint32_t room = held < ROWS_W ? ROWS_W - held : 0u;
+        ld += pend;
+        const uint32_t left = len - ld;
         uint32_t want = room < left ? room : left;
         want = want < ROWS_RQ_MAX ? want : ROWS_RQ_MAX;
         // (every lane issues the loads -- one that asks for nothing reads the rollout's own stream state into its slot, which
         // nobody looks at: a round then issues a fixed number of vector-memory instructions, ROWS_VM_REQ)
         const bool ok = mine && cl == li && want && (int64_t)beg + ld + 8 <= t.N;
         const uint32_t *src = ok ? dbase + beg + ld : (const uint32_t *)rng4;
-        lds_dma_x4(src, dma_a + DS_RQA * 256u);
-        if (ROWS_RQ_MAX > 4u) lds_dma_x4(ok && want > 4u ? src + 4 : (const uint32_t *)rng4, dma_a + DS_RQB * 256u);
+        lds_dma_x4(src, dma_a + rq.a);
+        if (ROWS_RQ_MAX > 4u) lds_dma_x4(ok && want > 4u ? src + 4 : (const uint32_t *)rng4, dma_a + rq.b);
         if (ok) {
             q_s = s_i;
             q_p = ld;
@@ -702,7 +749,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         // asks for that tick's top-ups late: on the XCDs with the longer memory latency 8 % of them then missed the next tick
         // and the windows ran dry half again as often (measured; tools/clock_rows.py).  At priority the round is short enough
         // everywhere; it costs the chain ~25 cycles per iteration of issue slots, which the steadier top-ups more than return.
-        __builtin_amdgcn_s_setprio(2);
+#ifndef ROWS_HELPER_PRIO
+#define ROWS_HELPER_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(ROWS_HELPER_PRIO);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LV32(sync_a + SY_GEN) = gen;  // the first 240 draws are in the ring
         uint32_t fin = 0;
@@ -751,10 +801,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #ifdef ROWS_DIAG_LAG
             lag_d2 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
 #endif
+            const RowsRq rq = rows_rq(ROWS_LAND_LAG == 2 && (k & 1u));  // this round's set of request areas (the chain landed it before it published the tick)
             {
+                // (first of all the set's descriptors go: the chain's dry-row path may look into the request areas at any time, and takes
+                // staged digests only under a descriptor that is still the same behind the read of the data)
+                LV32(dma_a + rq.d + lane * 4u) = 0u;
                 const scan_u32x4 none = {ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED, ROWS_NOT_LANDED};
-                LV128(dma_a + DS_RQA * 256u + lane * 16u) = none;
-                LV128(dma_a + DS_RQB * 256u + lane * 16u) = none;
+                LV128(dma_a + rq.a + lane * 16u) = none;
+                LV128(dma_a + rq.b + lane * 16u) = none;
             }
             const uint32_t la = rbase + ((k & 1u) ? RO_LOG2 : RO_LOG);
             const uint32_t n = LV32(sync_a + ((k & 1u) ? SY_N1 : SY_N0));
@@ -770,9 +824,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             {   // the window top-ups this tick's steps call for, first of all (the chain lands them at the end of its next tick:
                 // what has not arrived by then is lost)
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
-                request(li < n, le & F.smask, q_s, q_p, q_n);  // (its LDS reads return before the first load is issued: the marks are in place)
-                LV32(dma_a + DS_RQD * 256u + lane * 4u) = q_n ? (q_p | (q_n << 28)) : 0u;
-                LV32(dma_a + DS_RQS * 256u + lane * 4u) = q_s;
+                request(li < n, le & F.smask, q_s, q_p, q_n, rq, rows_rq(ROWS_LAND_LAG == 2 && !(k & 1u)), (k & 1u) != 0u, ROWS_LAND_LAG == 2 && k > 0u);  // (its LDS reads return before the first load is issued: the marks are in place)
+                LV32(dma_a + rq.d + lane * 4u) = q_n ? (q_p | (q_n << 28)) : 0u;
+                LV32(dma_a + rq.s + lane * 4u) = q_s;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
 #ifdef ROWS_DIAG_LAG
@@ -863,32 +917,173 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 }
             }
             PF_PH(7);
-            // One batch of reads: the flag of the helper's request round (it made the requests of the PREVIOUS tick's steps while
-            // this tick ran), the descriptors and digests of that round.  A flag that is not there yet is rare (the helper is a
-            // tick ahead); only then are the reads repeated behind a bounded wait.
-            const uint32_t v_req = LV32(sync_a + SY_REQ);
-            uint32_t dsc = dma_slot(DS_RQD), dss = dma_slot(DS_RQS);
-            in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
-            if (tick_k >= 1u) {
-                const uint32_t want_r = tick_k;
-                if (__ballot(v_req < want_r) != 0ull) {
+            // The flag of the helper's request round that lands now (it made the requests of tick tick_k - ROWS_LAND_LAG; with two sets
+            // of request areas it used set tick_k & 1).  A flag that is not there yet is rare; only then a bounded wait.
+            const RowsRq rq = rows_rq(ROWS_LAND_LAG == 2 && (tick_k & 1u));
+            if (tick_k >= (uint32_t)ROWS_LAND_LAG) {
+                const uint32_t want_r = tick_k + 1u - (uint32_t)ROWS_LAND_LAG;
+                if (__ballot(LV32(sync_a + SY_REQ) < want_r) != 0ull) {
                     if (!spin_until([&]() { return LV32(sync_a + SY_REQ) >= want_r; }) && !dead) {
                         status = OFFSIM_ST_PROTOCOL;
                         dead = 1u;
                     }
-                    dsc = dma_slot(DS_RQD), dss = dma_slot(DS_RQS);
-                    in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
                 }
+            }
+#ifdef ROWS_TICK_CXX
+            uint32_t dsc = LV32(dma_a + rq.d + lane * 4u), dss = LV32(dma_a + rq.s + lane * 4u);
+            in_a = LV128(dma_a + rq.a + lane * 16u), in_b = LV128(dma_a + rq.b + lane * 16u);
+            if (tick_k >= (uint32_t)ROWS_LAND_LAG) {
                 rq_p = dsc & 0xfffffffu;
                 rq_s = dss;
                 rq_n = dsc >> 28;  // (<= 8)
             }
+#else
+            // Landing and hand-off, hand-written (round 4; the compiled form of the same steps -- ROWS_TICK_CXX -- took ~1400 of the
+            // tick's 1950 cycles): lane = step of the round that lands.  One batch of reads (descriptor, state, the eight staged
+            // digests), a second one (the state's window row and its end), the count of entries the head-aligned row holds, the
+            // number k of staged digests that land -- the request was aimed at the window's end as it stands, its groups of four
+            // have arrived, the row has room -- and k stores under the lane masks k > i; then the tick's log (lane = step), its
+            // counters and the flag, behind the landing (one wavefront's DS instructions execute in issue order: data before flag).
+            // Entries are stored biased like everywhere else: max(digest - bias, ROWS_NEVER) with the subtraction saturating (for a
+            // digest within 0x200 of the bias this is ROWS_NEVER where rows_bias() keeps the difference: both are below every draw).
+            {
+                const uint32_t rqo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dma_a + rq.a));
+                // (wave-uniform by construction, but kept in VGPRs by the compiler: the scalar operands are read off lane 0)
+                const uint32_t landon = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tick_k >= (uint32_t)ROWS_LAND_LAG ? 1u : 0u));
+                const uint32_t na = sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0);
+                const uint32_t fin_v = (uint32_t)status + 1u, tk1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tick_k + 1u));
+                asm volatile(
+                    "s_mov_b64 s[34:35], exec\n\t"
+                    "s_cmp_eq_u32 %[landon], 0\n\t"
+                    "s_cbranch_scc1 5f\n\t"
+                    "v_add_u32 v80, %[rqo], %[lane4]\n\t"
+                    "v_lshl_add_u32 v83, %[lane4], 2, %[rqo]\n\t"
+                    "ds_read_b32 v81, v80 offset:2048\n\t"                 // descriptor: position | entries << 28
+                    "ds_read_b32 v82, v80 offset:2304\n\t"                 // ... and its state
+                    "ds_read_b128 v[84:87], v83\n\t"                       // digests 0..3
+                    "ds_read_b128 v[88:91], v83 offset:1024\n\t"           // digests 4..7
+                    "s_waitcnt lgkmcnt(2)\n\t"
+                    "v_lshrrev_b32 v92, 28, v81\n\t"                       // entries asked for
+                    "v_and_b32 v81, 0xfffffff, v81\n\t"                    // the window end the request was aimed at
+                    "v_cmp_ne_u32_e64 s[22:23], 0, v92\n\t"                // lanes with a request
+                    "v_mov_b32 v104, 0\n\t"
+                    "v_mov_b32 v105, 0\n\t"
+                    "v_cndmask_b32_e64 v82, 0, v82, s[22:23]\n\t"          // (a lane without one looks at state 0)
+                    "v_lshl_add_u32 v93, v82, 5, %[wina]\n\t"
+                    "v_lshl_add_u32 v94, v82, 2, %[landa]\n\t"
+                    "ds_read_b128 v[96:99], v93\n\t"                       // the window row as it stands
+                    "ds_read_b128 v[100:103], v93 offset:16\n\t"
+                    "ds_read_b32 v95, v94\n\t"                             // its end
+                    "s_waitcnt lgkmcnt(3)\n\t"                             // the staged digests
+                    "v_max3_u32 v106, v84, v85, v86\n\t"
+                    "v_max3_u32 v107, v88, v89, v90\n\t"
+                    "v_max_u32 v106, v106, v87\n\t"                        // all-ones: a group of four has not arrived
+                    "v_max_u32 v107, v107, v91\n\t"
+                    "v_sub_u32_e64 v84, v84, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v85, v85, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v86, v86, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v87, v87, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v88, v88, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v89, v89, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v90, v90, %[bias] clamp\n\t"
+                    "v_sub_u32_e64 v91, v91, %[bias] clamp\n\t"
+                    "v_max_u32 v84, 0x200, v84\n\t"
+                    "v_max_u32 v85, 0x200, v85\n\t"
+                    "v_max_u32 v86, 0x200, v86\n\t"
+                    "v_max_u32 v87, 0x200, v87\n\t"
+                    "v_max_u32 v88, 0x200, v88\n\t"
+                    "v_max_u32 v89, 0x200, v89\n\t"
+                    "v_max_u32 v90, 0x200, v90\n\t"
+                    "v_max_u32 v91, 0x200, v91\n\t"
+                    "v_cmp_ne_u32_e64 s[24:25], -1, v106\n\t"              // digests 0..3 have arrived
+                    "v_cmp_ne_u32_e64 s[26:27], -1, v107\n\t"              // digests 4..7 have arrived
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_min_u32 v96, 1, v96\n\t"                            // entries the row holds (head-aligned: they come first)
+                    "v_min_u32 v97, 1, v97\n\t"
+                    "v_min_u32 v98, 1, v98\n\t"
+                    "v_min_u32 v99, 1, v99\n\t"
+                    "v_min_u32 v100, 1, v100\n\t"
+                    "v_min_u32 v101, 1, v101\n\t"
+                    "v_min_u32 v102, 1, v102\n\t"
+                    "v_min_u32 v103, 1, v103\n\t"
+                    "v_add3_u32 v104, v96, v97, v98\n\t"
+                    "v_add3_u32 v105, v99, v100, v101\n\t"
+                    "v_add3_u32 v104, v104, v102, v103\n\t"
+                    "v_add_u32 v104, v104, v105\n\t"
+                    "v_cmp_eq_u32_e64 s[20:21], v81, v95\n\t"              // aimed at the end as it stands
+                    "s_and_b64 s[28:29], s[24:25], s[26:27]\n\t"
+                    "s_and_b64 s[20:21], s[20:21], s[22:23]\n\t"           // hit
+                    "v_min_u32 v105, 4, v92\n\t"
+                    "s_andn2_b64 s[30:31], s[22:23], s[20:21]\n\t"         // request that missed its window end
+                    "v_cndmask_b32_e64 v105, 0, v105, s[24:25]\n\t"        // the first group, if it is there
+                    "v_cndmask_b32_e64 v105, v105, v92, s[28:29]\n\t"      // everything, if both are
+                    "v_sub_u32 v106, 8, v104\n\t"                          // room
+                    "v_cndmask_b32_e64 v105, 0, v105, s[20:21]\n\t"
+                    "v_lshl_add_u32 v93, v104, 2, v93\n\t"                 // the row's end
+                    "v_min_u32 v105, v105, v106\n\t"                       // k: entries that land
+                    "v_addc_co_u32_e64 %[nreq], s[36:37], 0, %[nreq], s[22:23]\n\t"
+                    "v_addc_co_u32_e64 %[nmiss], s[36:37], 0, %[nmiss], s[30:31]\n\t"
+                    "s_andn2_b64 s[30:31], s[20:21], s[24:25]\n\t"         // hit, but not arrived
+                    "v_cmp_lt_u32_e32 vcc, 0, v105\n\t"
+                    "v_addc_co_u32_e64 %[nlate], s[36:37], 0, %[nlate], s[30:31]\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "v_add_u32 v95, v95, v105\n\t"
+                    "ds_write_b32 v93, v84\n\t"
+                    "ds_write_b32 v94, v95\n\t"                            // the window's new end
+                    "v_cmp_lt_u32_e32 vcc, 1, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v85 offset:4\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 2, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v86 offset:8\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 3, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v87 offset:12\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 4, v105\n\t"
+                    "s_cbranch_vccz 5f\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v88 offset:16\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 5, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v89 offset:20\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 6, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v90 offset:24\n\t"
+                    "v_cmp_lt_u32_e32 vcc, 7, v105\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 v93, v91 offset:28\n\t"
+                    "5:\n\t"
+                    "s_mov_b64 exec, s[34:35]\n\t"
+                    "ds_write_b32 %[loga], %[elog]\n\t"                     // the tick's sixteen log words, lane = step
+                    "ds_write_b32 %[na], %[nv]\n\t"
+                    "ds_write_b32 %[synca], %[cv] offset:8\n\t"            // SY_C
+                    "v_cmp_ne_u32_e32 vcc, 0, %[dead]\n\t"
+                    "v_mov_b32 v106, %[tk1]\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "ds_write_b32 %[synca], %[fin] offset:16\n\t"          // SY_FIN: the rows that have stopped
+                    "s_mov_b64 exec, s[34:35]\n\t"
+                    "ds_write_b32 %[synca], v106\n\t"                       // SY_TICK
+                    : [nreq] "+v"(n_req), [nmiss] "+v"(n_miss), [nlate] "+v"(n_late)
+                    : [rqo] "s"(rqo), [lane4] "v"(lane * 4u), [wina] "v"(win_a), [landa] "v"(land_a), [loga] "v"(log_a + li4), [elog] "v"(elog),
+                      [na] "v"(na), [nv] "v"(n), [synca] "v"(sync_a), [cv] "v"(c), [dead] "v"(dead), [fin] "v"(fin_v), [tk1] "s"(tk1),
+                      [landon] "s"(landon), [bias] "s"(F.bias)
+                    : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s34", "s35", "s36",
+                      "s37", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97",
+                      "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+                static_assert(SY_TICK == 0 && SY_C == 8 && SY_FIN == 16 && DS_RQD * 256 == 2048 && DS_RQS * 256 == 2304 && DS_RQB * 256 == 1024 && DS_RQA == 0,
+                              "the immediates of the hand-written tick");
+            }
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
             le = elog;  // (single wavefront: the log never leaves the registers)
             in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
         }
         PF_PH(0);
+#ifndef ROWS_TICK_CXX
+        if (!HELPER)
+#endif
+        {
         // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
         // covered meanwhile is skipped, whatever does not fit -- or has not arrived -- is requested again later.  The window is
         // head-aligned, so its end is the number of entries it holds.
@@ -930,6 +1125,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             if (k) LV32(land_a + rq_s * 4u) = land_ld + k;
             rq_n = 0;
         }
+        }
+#ifdef ROWS_TICK_CXX
         if (HELPER) {
             // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
             // order) -- BEHIND the landing: the helper aims its next requests at the windows' ends as it finds them, and a
@@ -943,6 +1140,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #endif
             LV32(sync_a + SY_TICK) = tick_k + 1u;
         }
+#endif
         PF_PH(2);
         if (HELPER) {
             steps += n;
@@ -951,7 +1149,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             logh_a = rbase + RO_LOGH + ((tick_k & 1u) ? 32u : 0u);
         } else {
             const uint32_t pos_i = positions(n, le);
-            request(li < n, le & F.smask, rq_s, rq_p, rq_n);
+            request(li < n, le & F.smask, rq_s, rq_p, rq_n, rows_rq(false), rows_rq(false), false, false);
             rewards_a();
             rewards_b(n, le, pos_i, !fmt_b ? 0u : (le >> 31) ? lds_r16(logh_a + li * 2u) : rows_loc_hi(le));
             if (!dead) {
@@ -1036,7 +1234,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_nop 1\n\t"                                                                                                 \
             "v_min_u32_dpp " KEY ", " KEY ", " KEY " row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                      \
             "v_and_b32 " ZN ", v113, " KEY "\n\t"                        /* next state (| done << 10: an event) */      \
-            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"             /* this lane's entry in the next state's row */ \
+            "v_lshl_add_u32 " RN ", " ZN ", 5, v109\n\t"                 /* this lane's entry in the next state's row */ \
             "ds_read_b32 " WN ", " RN "\n\t"                             /* next look's entry (ahead of the store: wrong if it is this state -- an event) */ \
             "v_add_u32_sdwa %[c4], %[c4], " KEY " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" /* + 4 x candidates consumed */ \
             "v_and_or_b32 %[nrd], %[c4], v115, %[ringa]\n\t"                                                              \
@@ -1074,7 +1272,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_mov_b64 exec, %[live]\n\t"                                                                                  \
             "ds_write_b32 %[tt], %[d]\n\t"                                                                                 \
             "s_waitcnt lgkmcnt(1)\n\t"                                  /* (the early entry read, the draw, the initial state) */ \
-            "v_lshl_add_u32 " RN ", " ZN ", 5, %[winrd]\n\t"                                                               \
+            "v_lshl_add_u32 " RN ", " ZN ", 5, v109\n\t"                                                                   \
             "ds_read_b32 " WN ", " RN "\n\t"                                                                               \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
             "s_branch " BACK "b\n\t"
@@ -1096,6 +1294,16 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #define ROWS_DRY_T1 "s_branch 52f\n\t"
 #else
 #define ROWS_DRY_T1
+#endif
+#ifdef ROWS_DRY_WHOLE16  /* (A/B build: sixteen candidates whatever the sector) */
+#define ROWS_DRY_SECTOR "v_mov_b32 v121, 16\n\t"
+#else
+#define ROWS_DRY_SECTOR
+#endif
+#ifdef ROWS_DRY_COUNT_HITS  /* (debug build: rows served from the request areas counted in bits 16.. of the dry counter) */
+#define ROWS_DRY_HITS "v_mov_b32 v99, 0x10000\n\t" "v_cndmask_b32_e64 v99, 0, v99, s[36:37]\n\t" "v_add_u32 %[ndry], %[ndry], v99\n\t"
+#else
+#define ROWS_DRY_HITS
 #endif
 #define ROWS_DRY_HANDLER                                                                                                     \
             "51:\n\t"                                                                                                     \
@@ -1145,22 +1353,96 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_cbranch_vccnz 2f\n\t"                                                                                      \
             "v_add_u32 v127, v127, %[li4]\n\t"                                                                            \
             "v_and_or_b32 v126, v127, v115, %[ringa]\n\t"                                                                 \
-            "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* grouped position of this lane's candidate */ \
+            /* ---- Is a top-up of this very window end waiting in the request areas?  (Two ticks pass between a request round and  */ \
+            /* its landing, ROWS_LAND_LAG: most of that time the digests are already on chip.)  The state's claim byte names, per    */ \
+            /* round parity, the lane that made the state's last request; its descriptor says whether it was aimed at the window end */ \
+            /* as it stands (= p), the first word of each group of four whether the group has arrived, and a second look at the      */ \
+            /* descriptor behind the data whether the helper has recycled the set meanwhile (it clears the descriptors first). */ \
+            "v_mbcnt_lo_u32_b32 v108, -1, 0\n\t"                                                                          \
+            "v_add_u32 v107, %[zz], %[claimb]\n\t"                                                                        \
+            "v_mbcnt_hi_u32_b32 v108, -1, v108\n\t"                                                                       \
+            "ds_read_u8 v107, v107\n\t"                                                                                   \
+            "v_lshlrev_b32 v108, 2, v108\n\t"                                                                             \
+            "v_sub_u32 v108, v108, %[li4]\n\t"                           /* 4 x the row's first lane */                  \
+            "v_add_u32 v108, %[dmaa], v108\n\t"                                                                           \
+            "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* (meanwhile) grouped position of this lane's candidate */ \
             "v_mov_b32 v125, 0\n\t"                                                                                       \
             "v_lshl_add_u64 v[124:125], v[124:125], 2, %[dbase]\n\t"                                                      \
-            /* Candidates up to the end of the 64-byte sector the queue's head lies in: the window's last top-up came out of that */ \
-            /* sector, so it is in L2 / the Infinity Cache (~300 cycles); the one behind it is an HBM round trip (~2500: measured).*/ \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_and_b32 v106, 15, v107\n\t"                               /* lane of the even rounds' request (set 0) */  \
+            "v_lshrrev_b32 v107, 4, v107\n\t"                            /* ... of the odd rounds' (set 1) */            \
+            "v_lshl_add_u32 v106, v106, 2, v108\n\t"                                                                      \
+            "v_lshl_add_u32 v107, v107, 2, v108\n\t"                                                                      \
+            "ds_read_b32 v100, v106 offset:2048\n\t"                     /* descriptor, state of set 0 */                \
+            "ds_read_b32 v101, v106 offset:2304\n\t"                                                                      \
+            "ds_read_b32 v102, v107 offset:4608\n\t"                     /* ... of set 1 */                              \
+            "ds_read_b32 v103, v107 offset:4864\n\t"                                                                      \
+            /* (meanwhile) candidates up to the end of the 64-byte sector the queue's head lies in: what the stream read may take */ \
             "v_lshrrev_b32 v121, 2, v124\n\t"                                                                             \
             "v_sub_u32 v121, v121, v118\n\t"                                                                              \
             "v_and_b32 v121, 15, v121\n\t"                                                                                \
-            "v_sub_u32 v121, 16, v121\n\t"                             /* candidates in the sector, 1..16 (the same in every lane of the row) */ \
+            "v_sub_u32 v121, 16, v121\n\t"                                                                                \
+            ROWS_DRY_SECTOR                                                                                                \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_and_b32 v104, 0xfffffff, v100\n\t"                                                                         \
+            "v_and_b32 v105, 0xfffffff, v102\n\t"                                                                         \
+            "v_cmp_eq_u32_e64 s[36:37], v101, %[zz]\n\t"                                                                  \
+            "v_cmp_eq_u32_e64 s[38:39], v104, %[e]\n\t"                                                                   \
+            "v_cmp_eq_u32_e64 s[40:41], v103, %[zz]\n\t"                                                                  \
+            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                  \
+            "v_cmp_eq_u32_e64 s[38:39], v105, %[e]\n\t"                                                                   \
+            "v_lshrrev_b32 v104, 28, v100\n\t"                           /* entries asked for */                         \
+            "v_lshrrev_b32 v105, 28, v102\n\t"                                                                            \
+            "s_and_b64 s[40:41], s[40:41], s[38:39]\n\t"                                                                  \
+            "v_cmp_ne_u32_e64 s[38:39], 0, v104\n\t"                                                                      \
+            "v_cmp_ne_u32_e32 vcc, 0, v105\n\t"                                                                           \
+            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                 /* set 0 holds a request for this window end */ \
+            "s_and_b64 s[40:41], s[40:41], vcc\n\t"                      /* set 1 does */                                \
+            "s_andn2_b64 s[40:41], s[40:41], s[36:37]\n\t"                                                                \
+            "v_mov_b32 v99, 0xa00\n\t"                                   /* from one set of request areas to the other */ \
+            "v_cndmask_b32_e64 v100, v100, v102, s[40:41]\n\t"           /* the descriptor that counts */                \
+            "v_cndmask_b32_e64 v104, v104, v105, s[40:41]\n\t"                                                            \
+            "v_cndmask_b32_e64 v106, v106, v107, s[40:41]\n\t"                                                            \
+            "v_cndmask_b32_e64 v99, 0, v99, s[40:41]\n\t"                                                                 \
+            "s_or_b64 s[36:37], s[36:37], s[40:41]\n\t"                                                                   \
+            "v_subrev_u32 v105, %[dmaa], v106\n\t"                       /* 4 x the requesting lane */                   \
+            "v_add_u32 v106, v106, v99\n\t"                              /* its descriptor (offset 2048) */              \
+            "v_lshl_add_u32 v105, v105, 2, %[dmaa]\n\t"                  /* its four staged digests */                   \
+            "s_and_b64 s[36:37], s[36:37], s[30:31]\n\t"                 /* (dry rows only) */                           \
+            "v_add_u32 v105, v105, v99\n\t"                                                                               \
+            "s_mov_b64 exec, s[36:37]\n\t"                                                                                \
+            "ds_read_b32 v97, v105\n\t"                                  /* first word of each group: all-ones = not arrived */ \
+            "ds_read_b32 v98, v105 offset:1024\n\t"                                                                       \
+            "v_and_b32 v102, 12, %[li4]\n\t"                                                                              \
+            "v_and_b32 v103, 16, %[li4]\n\t"                                                                              \
+            "v_lshl_add_u32 v102, v103, 6, v102\n\t"                     /* lane 0..3: first group, 4..7: second group */ \
+            "v_add_u32 v105, v105, v102\n\t"                                                                              \
+            "ds_read_b32 v101, v105\n\t"                                 /* this lane's staged candidate (lanes 8..15: not used) */ \
+            "ds_read_b32 v96, v106 offset:2048\n\t"                      /* the descriptor once more, behind the data */ \
+            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
+            "v_cmp_lt_u32_e32 vcc, 4, v104\n\t"                                                                           \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_cmp_ne_u32_e64 s[38:39], -1, v97\n\t"                     /* the first group has arrived */               \
+            "v_cmp_ne_u32_e64 s[40:41], -1, v98\n\t"                                                                      \
+            "s_and_b64 s[40:41], s[40:41], vcc\n\t"                      /* the second group was asked for and has arrived */ \
+            "v_cmp_eq_u32_e32 vcc, v96, v100\n\t"                        /* the set has not been recycled */             \
+            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                  \
+            "v_cndmask_b32_e64 v104, 4, 8, s[40:41]\n\t"                 /* staged candidates */                         \
+            "s_and_b64 s[36:37], s[36:37], vcc\n\t"                      /* rows served from the request areas */        \
+            "s_nop 0\n\t"                                                                                                 \
+            "v_cndmask_b32_e64 v121, v121, v104, s[36:37]\n\t"           /* candidates at hand: the staged ones, or the sector's */ \
             "v_cmp_lt_u32_e32 vcc, v118, v121\n\t"                                                                        \
             "s_mov_b64 exec, s[30:31]\n\t"                                                                                \
             "v_mov_b32 %[zn], -1\n\t"                                  /* (a lane without a candidate accepts nothing) */ \
             "s_and_b64 exec, exec, vcc\n\t"                                                                               \
+            "s_mov_b64 s[38:39], exec\n\t"                                                                                \
+            "s_andn2_b64 exec, exec, s[36:37]\n\t"                       /* the other rows read the stream */            \
             "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
+            "s_mov_b64 exec, s[38:39]\n\t"                                                                                \
             "ds_read_b32 v117, v126\n\t"                                 /* draw c + hv + lane */                        \
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                           \
+            "v_cndmask_b32_e64 %[w2], %[w2], v101, s[36:37]\n\t"                                                          \
+            ROWS_DRY_HITS                                                                                                  \
             "v_cmp_lt_u32_e32 vcc, 0x8000, %[w2]\n\t"                    /* the window's bias (rows_bias) */             \
             "v_add_u32 v122, 0xffff8000, %[w2]\n\t"                                                                       \
             "v_mov_b32 v125, 0x200\n\t"                                  /* ROWS_NEVER (a literal and vcc do not share the constant bus) */ \
@@ -1227,7 +1509,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_and_or_b32 %[nrd], %[c4], v115, %[ringa]\n\t"                                                              \
             "ds_read_b32 %[kt], %[nrd]\n\t"                                                                               \
             "s_waitcnt lgkmcnt(1)\n\t"                                                                                    \
-            "v_lshl_add_u32 %[ra], %[zz], 5, %[winrd]\n\t"                                                                \
+            "v_lshl_add_u32 %[ra], %[zz], 5, v109\n\t"                                                                    \
             "ds_read_b32 %[w], %[ra]\n\t"                                /* behind every store of the step */            \
             "s_add_u32 %[it], %[it], 1\n\t"                                                                               \
             "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the entry code copies w and kt into the second register set) */ \
@@ -1247,12 +1529,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_mov_b32 s26, 0x10001\n\t"                                 /* s[26:27]: lane 0 of every row */              \
             "s_mov_b32 s27, 0x10001\n\t"                                                                                  \
             "v_and_b32 v110, 28, %[li4]\n\t"                                                                              \
+            "v_add_u32 v109, 0x5c0, %[ringa]\n\t"                        /* RO_WIN behind RO_RING */                     \
             "v_mov_b32 v112, " SPAY "\n\t"                                                                                \
             "v_mov_b32 v113, " SZM "\n\t"                                                                                 \
             "v_add_u32 v111, 4, v110\n\t"                                                                                 \
             "v_mov_b32 v114, " SAMB "\n\t"                                                                                \
             "v_mov_b32 v115, 0x3fc\n\t"                                                                                   \
             "v_lshlrev_b32 v111, 24, v111\n\t"                                                                            \
+            "v_add_u32 v109, v109, v110\n\t"                             /* this lane's entry of state 0's window row */ \
             "v_mov_b32 v116, " SKM "\n\t"                                                                                 \
             "40:\n\t"                                                                                                     \
             "v_mov_b32 %[zn], %[zz]\n\t"                                 /* both register sets hold the row state: any copy may be the first */ \
@@ -1340,10 +1624,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             : [w] "+v"(w), [kt] "+v"(kt), [c4] "+v"(c4), [ra] "+v"(ra), [zz] "+v"(zz), [initp] "+v"(initp), [left] "+v"(left), [key] "+v"(key),         \
               [elog] "+v"(elog), [ndry] "+v"(n_dry), [key2] "=&v"(key2), [d] "=&v"(d), [tt] "=&v"(tt), [nrd] "=&v"(nrd), [e] "=&v"(e), [zn] "=&v"(zn),  \
               [rb] "=&v"(rb), [w2] "=&v"(w2), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)                                                           \
-            : [ringa] "v"(ring_a), [winrd] "v"(win_rd_l), [li4] "v"(li4), [landb] "v"(land_a), [gen4] "v"(gen4), [dbase] "v"(dbase), [sega] "s"(seg_a),  \
+            : [ringa] "v"(ring_a), [claimb] "v"(claim_a), [dmaa] "s"(dma_a), [li4] "v"(li4), [landb] "v"(land_a), [gen4] "v"(gen4), [dbase] "v"(dbase), [sega] "s"(seg_a),  \
               [live] "s"(live)                                                                                                                           \
             : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s30", "s31", "s32", "s33", "v110", "v111", "v112",        \
-              "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+              "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v96", "v97",       \
+              "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "s36", "s37", "s38", "s39", "s40", "s41")
+        static_assert(RO_WIN - RO_RING == 0x5c0u && DS_RQD * 256u == 2048u && DS_RQS * 256u == 2304u && DS_RQ_SET * 256u == 2560u && DS_RQB * 256u == 1024u, "immediates of the loop");
         static_assert(rows_format(OFFSIM_STREAMS_A).paymask == 0x7ffu && rows_format(OFFSIM_STREAMS_A).zmask == 0x7ffu &&
                       rows_format(OFFSIM_STREAMS_A).amb == 0xffff7800u && (rows_format(OFFSIM_STREAMS_A).emask | 0x400u) == 0x3c000400u &&
                       rows_format(OFFSIM_STREAMS_A).bias == 0x8000u && rows_format(OFFSIM_STREAMS_A).smask == 0x3ffu, "the literals of the format-A loop");
@@ -1352,7 +1638,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         if constexpr (fmt_b) {
             ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
         } else {
-#ifdef ROWS_NO_DRY_ASM  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
+#if defined(ROWS_NO_DRY_ASM) || ROWS_LAND_LAG != 2  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "6", "");
 #else
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER);
