@@ -153,6 +153,50 @@ int offsim_step_batch(const offsim_table *t, offsim_rollouts *ro, const void *p_
                       int32_t reject_mode, int32_t advance, int32_t *out_row, int32_t *out_status,
                       uint32_t *out_popped, void *stream);
 
+/* ---- step server: PSRS.step for one environment without a launch per call (a4, a7) ----------------------------------
+ * The reference's evaluator is driven by one Python call per simulated step (per_state_rejection.py:85-95); a kernel launch plus a
+ * stream synchronise per call costs ~27 us against ~9 us for the reference's own Python step.  offsim_step_server_start leaves ONE
+ * wavefront resident that serves offsim_step_batch's step (R = 1, same arithmetic, same state rows) for requests posted through a
+ * mailbox in host-coherent pinned memory:
+ *   host:   write p_new (p_head / p_tail) and cmd / reject_mode, then seq_in2 = previous seq_in + 1, THEN seq_in = the same
+ *           wait until seq_out == seq_in, read row / status / popped
+ *   device: ends on OFFSIM_SERVER_CMD_EXIT, or by itself after `idle_polls` polls (~1-2 us each) without a request: `state` says so,
+ *           and the host starts it again.  While it runs, nothing else may touch the rollout's state rows (cursor, rng, cur_slot).
+ * offsim_host_alloc / offsim_host_free: the mailbox's memory (hipHostMalloc, coherent + mapped: host and device see each other's
+ * stores while the kernel runs).  `stream` must not be a stream the caller synchronises while the server is meant to stay up. */
+#define OFFSIM_MAILBOX_MAX_ACTIONS 24
+#define OFFSIM_SERVER_CMD_STEP 1     /* PSRS.step(p_new) */
+#define OFFSIM_SERVER_CMD_POP_ONE 2  /* pop one candidate, accept it, leave the state (the Python-side _reject hook's primitive) */
+#define OFFSIM_SERVER_CMD_EXIT 3
+#define OFFSIM_SERVER_CMD_RESET 4    /* PSRS.reset (psrs.py:32-37): row = caller-buffer row of the initial state, or -1 */
+#define OFFSIM_SERVER_STARTING 1
+#define OFFSIM_SERVER_RUNNING 2
+#define OFFSIM_SERVER_EXITED 3
+typedef struct offsim_step_mailbox {
+    /* the first 64 bytes are what ONE poll of the server reads */
+    uint32_t seq_in;      /* host -> device: request number, written LAST */
+    uint32_t cmd;         /* OFFSIM_SERVER_CMD_* */
+    int32_t reject_mode;  /* OFFSIM_REJECT_* */
+    uint32_t reserved0;
+    double p_head[5];     /* p_new[0..4] (f64), or p_new[0..9] as packed f32 (OFFSIM_PROB_F32) */
+    uint32_t reserved1;
+    uint32_t seq_in2;     /* the request number once more, written BEFORE seq_in and behind everything else: a snapshot of the 64 bytes
+                           * that shows the new number in both places holds the new payload, whatever order its parts were read in */
+    double p_tail[OFFSIM_MAILBOX_MAX_ACTIONS - 5]; /* p_new[5..] (f64), or p_new[10..] as packed f32 */
+    uint32_t reserved2[2];
+    /* the answer: one 16-byte store of the device */
+    uint32_t seq_out;     /* device -> host: the request served */
+    int32_t row;          /* caller-buffer row of the accepted transition (RESET: of the initial state), or -1 */
+    int32_t status;       /* OFFSIM_ST_* */
+    uint32_t popped;      /* candidates consumed */
+    uint32_t state;       /* OFFSIM_SERVER_* (0: never started) */
+    uint32_t reserved3[3];
+} offsim_step_mailbox;
+int offsim_host_alloc(int64_t bytes, void **host_ptr);
+int offsim_host_free(void *host_ptr);
+int offsim_step_server_start(const offsim_table *t, offsim_rollouts *ro, offsim_step_mailbox *mailbox, int32_t prob_mode,
+                             uint32_t idle_polls, void *stream);
+
 /* Sets the current state of masked rollouts (used after a Python-side accept): cur_slot[r] = slot[r]. */
 int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream);
 

@@ -58,6 +58,19 @@ class TD(C.Structure):
                 ("tie_mt", _vp), ("beh_arg", _vp)]
 
 
+MAILBOX_MAX_ACTIONS = 24
+SERVER_CMD_STEP, SERVER_CMD_POP_ONE, SERVER_CMD_EXIT, SERVER_CMD_RESET = 1, 2, 3, 4
+SERVER_STARTING, SERVER_RUNNING, SERVER_EXITED = 1, 2, 3
+
+
+class StepMailbox(C.Structure):
+    """struct offsim_step_mailbox (host-coherent pinned memory shared with the resident step server)"""
+    _fields_ = [("seq_in", C.c_uint32), ("cmd", C.c_uint32), ("reject_mode", _i32), ("reserved0", C.c_uint32), ("p_head", C.c_double * 5),
+                ("reserved1", C.c_uint32), ("seq_in2", C.c_uint32), ("p_tail", C.c_double * (MAILBOX_MAX_ACTIONS - 5)),
+                ("reserved2", C.c_uint32 * 2), ("seq_out", C.c_uint32), ("row", _i32), ("status", _i32), ("popped", C.c_uint32),
+                ("state", C.c_uint32), ("reserved3", C.c_uint32 * 3)]
+
+
 TD_QLEARN, TD_EXPSARSA = 1, 2
 BEHAVIOUR_FIXED, BEHAVIOUR_EPS_GREEDY, BEHAVIOUR_SOFT_GREEDY = 0, 1, 2
 
@@ -94,6 +107,9 @@ SIGNATURES = {
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
     "offsim_selftest_lds_atomic_order": (C.c_int, [_vp, _vp]),
+    "offsim_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
+    "offsim_host_free": (C.c_int, [_vp]),
+    "offsim_step_server_start": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_uint32, _vp]),
     "offsim_async_faults": (C.c_int, []),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
     "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),

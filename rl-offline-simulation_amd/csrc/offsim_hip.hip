@@ -1082,6 +1082,153 @@ extern "C" int offsim_step_batch(const offsim_table *t, offsim_rollouts *ro, con
     return OFFSIM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Step server: PSRS.step for ONE environment without a kernel launch per call (per_state_rejection.py:85-95 is one Python call per
+// simulated step; a launch + stream synchronise is ~27 us).  One wavefront stays resident and serves requests posted through a mailbox in
+// host-coherent pinned memory (include/offsim.h: offsim_step_mailbox): the host writes p_new and the command, then the request number;
+// the wavefront polls the request number (system-scope loads over PCIe), runs exactly the step k_step_batch runs -- same psrs_step, same
+// stream arithmetic, state written back to the rollout's rows after every step -- and answers with row / status / popped and the request
+// number.  It ends on command, or by itself after `idle_polls` polls without a request, so that a device-wide synchronise elsewhere in
+// the process waits milliseconds at most; the host starts it again on demand.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T sys_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <typename T>
+__device__ __forceinline__ void sys_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <typename PL, typename PROB>
+__global__ void __launch_bounds__(64) k_step_server(offsim_table t, offsim_rollouts ro, offsim_step_mailbox *mb, uint32_t idle_polls) {
+    __shared__ Jump table[WAVE + 1];
+    __shared__ PROB p_sh[OFFSIM_MAILBOX_MAX_ACTIONS];
+    const int lane = threadIdx.x & (WAVE - 1);
+    uint32_t last = sys_load(&mb->seq_out);
+    if (lane == 0) sys_store(&mb->state, (uint32_t)OFFSIM_SERVER_RUNNING);
+    // the environment's state stays in registers between requests (and is written through to its rows after every one: whoever stops
+    // the server finds them current)
+    int slot = ro.cur_slot[0];
+    U128 base = u128(ro.rng[0], ro.rng[1]);
+    const U128 inc = u128(ro.rng[2], ro.rng[3]);
+    const uint32_t *head = (const uint32_t *)mb;
+    for (;;) {
+        // One poll = ONE read of the mailbox's first 64 bytes (lane i: dword i): request number, command, reject mode, the first
+        // probabilities, and the request number once more in the line's last dword -- the host writes that one before the first, so a
+        // snapshot that shows both holds the payload between them, whatever order its halves were read in.
+        uint32_t seq = last, polls = 0, w = 0;
+        for (;;) {
+            w = lane < 16 ? sys_load(head + lane) : 0u;
+            seq = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
+            if (seq != last && (uint32_t)__builtin_amdgcn_readlane((int)w, 15) == seq) break;
+            if (++polls > idle_polls) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (seq == last || (uint32_t)__builtin_amdgcn_readlane((int)w, 15) != seq) break;  // idle: end (the host starts the server again with its next request)
+        const uint32_t cmd = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
+        const int reject_mode = __builtin_amdgcn_readlane((int)w, 2);
+        if (cmd == OFFSIM_SERVER_CMD_EXIT) {
+            if (lane == 0) sys_store(&mb->seq_out, seq);
+            break;
+        }
+        int32_t row = -1, status = OFFSIM_ST_INACTIVE;
+        uint32_t popped = 0;
+        if (cmd == OFFSIM_SERVER_CMD_RESET) {  // PSRS.reset (psrs.py:32-37), as k_env_reset
+            const uint32_t ic = ro.init_cursor[0];
+            status = OFFSIM_ST_OK;
+            if ((int64_t)ic >= t.N0) {
+                slot = -1;
+            } else {
+                const uint32_t k = ro.init_perm ? ro.init_perm[ic] : ic;
+                if (lane == 0) ro.init_cursor[0] = ic + 1;
+                slot = t.init_slot[k];
+                row = t.init_orig[k];
+            }
+            if (lane == 0) ro.cur_slot[0] = slot;
+        } else {
+            // probabilities: the first five doubles (ten floats) came with the poll, the others are read now
+            constexpr int in_head = sizeof(PROB) == 8 ? 5 : 10;
+            if (sizeof(PROB) == 8) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane * 2 + 4) & 63) * 4, (int)w);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane * 2 + 5) & 63) * 4, (int)w);
+                if (lane < in_head && lane < t.nA) ((double *)p_sh)[lane] = __hiloint2double((int)hi, (int)lo);
+            } else {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 4) & 63) * 4, (int)w);
+                if (lane < in_head && lane < t.nA) ((float *)p_sh)[lane] = __uint_as_float(v);
+            }
+            if (lane >= in_head && lane < t.nA) p_sh[lane] = sys_load((const PROB *)mb->p_tail + (lane - in_head));
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const int advance = cmd == OFFSIM_SERVER_CMD_STEP ? 1 : 0;
+            const uint32_t max_pop = cmd == OFFSIM_SERVER_CMD_POP_ONE ? 1u : 0u;
+            if (slot >= 0) {
+                WaveRng rng;
+                rng.kind = ro.rng_kind;
+                if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc, ro.rng_kind);
+                uint64_t consumed = 0;
+                const StepResult s = psrs_step<PL, PROB>(t, t.seg_off, ro.perm, slot, ro.cursor, p_sh, reject_mode, max_pop, rng, consumed);
+                if (consumed && ro.rng_kind == OFFSIM_STREAM_PHILOX) {
+                    base.lo += consumed;
+                    if (lane == 0) ro.rng[1] = base.lo;
+                } else if (consumed) {
+                    base = pcg_apply(pcg_jump(inc, consumed), base);
+                    if (lane == 0) {
+                        ro.rng[0] = base.hi;
+                        ro.rng[1] = base.lo;
+                    }
+                }
+                if (s.status == OFFSIM_ST_OK && advance) {  // psrs.py:49-50
+                    slot = s.z_next;
+                    if (lane == 0) ro.cur_slot[0] = slot;
+                }
+                row = s.status == OFFSIM_ST_OK ? t.orig_idx[s.g] : -1;
+                status = s.status;
+                popped = s.popped;
+            }
+        }
+        if (lane == 0) {  // the answer: one 16-byte store (request number, row, status, popped)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 ans = {seq, (uint32_t)row, (uint32_t)status, popped};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&mb->seq_out), "v"(ans) : "memory");
+        }
+        last = seq;
+    }
+    __threadfence_system();
+    if (lane == 0) sys_store(&mb->state, (uint32_t)OFFSIM_SERVER_EXITED);
+}
+
+extern "C" int offsim_host_alloc(int64_t bytes, void **host_ptr) {
+    if (bytes <= 0 || !host_ptr) return fail(OFFSIM_EINVAL, "host_alloc: bad argument%s");
+    void *p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, (size_t)bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p, 0, (size_t)bytes);
+    *host_ptr = p;
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_host_free(void *host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return OFFSIM_OK;
+}
+
+extern "C" int offsim_step_server_start(const offsim_table *t, offsim_rollouts *ro, offsim_step_mailbox *mailbox, int32_t prob_mode,
+                                        uint32_t idle_polls, void *stream) {
+    int rc = check_table(t);
+    if (rc) return rc;
+    if (!ro || ro->R != 1 || !mailbox) return fail(OFFSIM_EINVAL, "step_server_start: one rollout and a mailbox%s");
+    if (ro->perm && ro->perm_stride < 0) return fail(OFFSIM_EINVAL, "step_server_start: bad perm%s");
+    if (t->nA > OFFSIM_MAILBOX_MAX_ACTIONS) return fail(OFFSIM_EUNSUPPORTED, "step_server_start: more actions than the mailbox holds (use offsim_step_batch)%s");
+    if (prob_mode == OFFSIM_PROB_F32 && t->plog_dtype != OFFSIM_F32) return fail(OFFSIM_EINVAL, "step_server_start: OFFSIM_PROB_F32 needs an f32 p_log%s");
+    void *dev_mb = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev_mb, mailbox, 0));
+    mailbox->state = OFFSIM_SERVER_STARTING;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_SERVER(PL, PROB) hipLaunchKernelGGL((k_step_server<PL, PROB>), dim3(1), dim3(WAVE), 0, st, *t, *ro, (offsim_step_mailbox *)dev_mb, idle_polls)
+    if (prob_mode == OFFSIM_PROB_F32) LAUNCH_SERVER(float, float);
+    else if (t->plog_dtype == OFFSIM_F32) LAUNCH_SERVER(float, double);
+    else if (t->plog_dtype == OFFSIM_F64) LAUNCH_SERVER(double, double);
+    else LAUNCH_SERVER(__half, double);
+#undef LAUNCH_SERVER
+    LAUNCH_CHECK();
+    return OFFSIM_OK;
+}
+
 extern "C" int offsim_eval_mc(const offsim_table *t, offsim_rollouts *ro, const void *pi, int32_t prob_mode,
                               int32_t reject_mode, double gamma, const double *gamma_pow, int64_t n_gamma_pow,
                               int64_t max_episodes, const offsim_evalmc_out *out, void *stream) {

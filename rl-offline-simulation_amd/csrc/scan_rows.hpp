@@ -903,10 +903,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             // have arrived (what has not by then is a top-up lost): the two counters the next tick needs, the initial-state ring.
             v_ht = LV32(sync_a + SY_HTICK);
             v_gen = LV32(sync_a + SY_GEN);
+            const uint32_t v_req = LV32(sync_a + SY_REQ);  // (one batch of reads, one wait)
             if (!dead) {
                 prefetch_step();
                 // the buffer of the next tick was read by the helper two ticks ago, and the ring holds a tick's worth of draws
-                const uint32_t want_h = tick_k;
+                // (format A: the tick's log lives in registers until the flush below, which overwrites the log of two ticks ago -- the helper
+                // may be a whole tick behind; format B writes the side bytes of the NEXT tick's long-form steps as they happen, into the
+                // half the helper reads for the tick before this one)
+                const uint32_t want_h = fmt_b ? tick_k : (tick_k ? tick_k - 1u : 0u);
                 if (__ballot(v_ht < want_h) != 0ull && !spin_until([&]() { return LV32(sync_a + SY_HTICK) >= want_h; })) {
                     status = OFFSIM_ST_PROTOCOL;
                     dead = 1u;
@@ -922,7 +926,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const RowsRq rq = rows_rq(ROWS_LAND_LAG == 2 && (tick_k & 1u));
             if (tick_k >= (uint32_t)ROWS_LAND_LAG) {
                 const uint32_t want_r = tick_k + 1u - (uint32_t)ROWS_LAND_LAG;
-                if (__ballot(LV32(sync_a + SY_REQ) < want_r) != 0ull) {
+                if (__ballot(v_req < want_r) != 0ull) {
                     if (!spin_until([&]() { return LV32(sync_a + SY_REQ) >= want_r; }) && !dead) {
                         status = OFFSIM_ST_PROTOCOL;
                         dead = 1u;

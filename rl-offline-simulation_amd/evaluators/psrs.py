@@ -93,6 +93,7 @@ class BatchedPSRS:
         result; it lets the sampler reset write the queue orders as the candidate streams the row-packed scan reads
         sequentially (offsim_shuffle_queues_keys: digest + 16-bit local row per queue position) instead of as permutations.
         (step / step_single / eval_td / the generic eval_mc need permutations and rebuild them from the streams on first use.)"""
+        self._quiesce()
         t, dev = self.table, self.table.device
         sd = seeds_tensor(seeds, dev)
         assert sd.numel() == self.R, "one seed per rollout"
@@ -147,8 +148,8 @@ class BatchedPSRS:
     def _shuffle_workspace(self, n_orders=None):
         """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to
         four persistent workgroups per compute unit -- no more than there are chains (`n_orders` queue orders x (states + 1)), nor than
-        keeps each busy with about four of the longest -- within a budget of the free HBM (`ws_budget_frac`, default 85 %, and never the
-        last `ws_keep_free` bytes, default 4 GiB: the policy's key buffer, rebuilt permutations, snapshots and outputs of the same
+        keeps each busy with about four of the longest -- within a budget of the free HBM (`ws_budget_frac`, default 92 %, and never the
+        last `ws_keep_free` bytes, default 2 GiB: the policy's key buffer, rebuilt permutations, snapshots and outputs of the same
         job are allocated later; a workgroup's pools are ~22 bytes per row of the longest chain).  None (the in-place shuffle) when the
         table has no such chain, when OFFSIM_SHUFFLE_CHUNKED=0, or when not even one workgroup's pools fit the budget."""
         t = self.table
@@ -170,7 +171,7 @@ class BatchedPSRS:
             self._ws = None  # (released first: what it held counts as free)
             torch.cuda.empty_cache()
             free = torch.cuda.mem_get_info(t.device)[0]
-            budget = min(int(free * getattr(self, "ws_budget_frac", 0.85)), free - int(getattr(self, "ws_keep_free", 4 << 30)))
+            budget = min(int(free * getattr(self, "ws_budget_frac", 0.92)), free - int(getattr(self, "ws_keep_free", 2 << 30)))
             n = min(want, max(0, (budget - head) // max(one - head, 1)))
             if n < 1 and have_bytes:  # nothing bigger fits: what there was is put back
                 n = max(0, (have_bytes - head) // max(one - head, 1))
@@ -319,6 +320,7 @@ class BatchedPSRS:
         provider = "pcg64": default_rng(seed) -- the reference's numbers.  provider = "philox": rocRAND's Philox4x32-10 through its
         device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by step / step_single / eval_td
         and the generic eval_mc (the compiled-policy scans draw from PCG64 only); reset_sampler puts PCG64 back."""
+        self._quiesce()
         sd = seeds_tensor(seeds, self.table.device)
         assert sd.numel() == self.R, "one seed per rollout"
         if provider == "pcg64":
@@ -337,11 +339,13 @@ class BatchedPSRS:
         permutations.  After reset_sampler(policy=...) the orders exist only as candidate streams: the permutations are rebuilt
         from the streams' local rows here, once (4 * R * N bytes) -- never left as table order by default."""
         if self.state.perm is None and self._perm_lazy == "streams":
+            self._quiesce()
             self.state.set_orders(self.perm.contiguous(), self.table.N, self.state.init_perm, self.state.init_stride)
             self._perm_buf = self.state.perm
 
     # -- PSRS.reset (psrs.py:32-37) --
     def reset(self, mask=None):
+        self._quiesce()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         L.check(L.load().offsim_env_reset(C.byref(self.table.c), C.byref(self.state.c), L.ptr(m), L.ptr(self._row), L.stream_ptr()))
         return self._row
@@ -349,6 +353,7 @@ class BatchedPSRS:
     # -- PSRS.step (psrs.py:39-51) --
     def step(self, p_new, advance=True, reject_mode=None):
         """p_new: [R,nA] tensor/array.  Returns device tensors (row, status, popped)."""
+        self._quiesce()
         self._orders_for_generic()
         t = self.table
         if not isinstance(p_new, torch.Tensor):
@@ -361,13 +366,19 @@ class BatchedPSRS:
         return self._row, self._status, self._popped
 
     def step_single(self, p_new, advance=True, reject_mode=None):
-        """R = 1 convenience for the drop-in classes: one launch per call.  The kernel reads p_new from, and writes
-        (row, status, popped) to, pinned host memory mapped into the device's address space, so that no copy is enqueued:
-        the call is launch + stream synchronise.  Returns host ints (row, status, popped)."""
-        self._orders_for_generic()
+        """R = 1 convenience for the drop-in classes (per_state_rejection.py:85-95 is one Python call per simulated step): the step is
+        served by a RESIDENT wavefront (offsim_step_server_start: no kernel launch, no stream synchronise per call -- ~27 us before)
+        through a mailbox in host-coherent pinned memory; the server is started on first use, ends by itself when idle, and is stopped
+        before anything else touches this environment's state (`_quiesce`).  OFFSIM_STEP_SERVER=0, more than 24 actions, or R != 1: one
+        launch per call, p_new and the results in pinned mapped memory.  Returns host ints (row, status, popped)."""
         t = self.table
         p_new = np.asarray(p_new)
         mode = _prob_mode(t, p_new.dtype)
+        rm = self.reject_mode if reject_mode is None else reject_mode
+        if self.R == 1 and t.nA <= L.MAILBOX_MAX_ACTIONS and os.environ.get("OFFSIM_STEP_SERVER", "1") != "0" and (advance or rm == L.REJECT_NEVER):
+            return self._server_step(p_new, mode, L.SERVER_CMD_STEP if advance else L.SERVER_CMD_POP_ONE, rm)
+        self._quiesce()
+        self._orders_for_generic()
         key = (mode, t.nA)
         if getattr(self, "_single_key", None) != key:
             dt = torch.float32 if mode == L.PROB_F32 else torch.float64
@@ -376,7 +387,6 @@ class BatchedPSRS:
             self._p_np, self._o_np = self._p_host.numpy(), self._o_host.numpy()
             self._single_key = key
         self._p_np[0, :] = p_new.reshape(-1)
-        rm = self.reject_mode if reject_mode is None else reject_mode
         base = self._o_host.data_ptr()
         L.check(L.load().offsim_step_batch(C.byref(t.c), C.byref(self.state.c), self._p_host.data_ptr(), mode, rm, 1 if advance else 0,
                                            base, base + 4, base + 8, L.stream_ptr()))
@@ -385,7 +395,100 @@ class BatchedPSRS:
         self.last_row = row
         return row, status, popped
 
+    # ---- the resident step server (include/offsim.h: offsim_step_server_start) ----
+    _SERVER_IDLE_POLLS = 20000  # polls of ~1-2 us without a request before the server ends by itself
+
+    def _server_start(self, mode):
+        lib = L.load()
+        if getattr(self, "_mb", None) is None:
+            ptr = C.c_void_p()
+            L.check(lib.offsim_host_alloc(C.sizeof(L.StepMailbox), C.byref(ptr)))
+            self._mb_ptr = ptr.value
+            self._mb = L.StepMailbox.from_address(ptr.value)
+            view = lambda f, n: np.ctypeslib.as_array((C.c_double * n).from_address(ptr.value + getattr(L.StepMailbox, f).offset))
+            self._mb_head64, self._mb_tail64 = view("p_head", 5), view("p_tail", L.MAILBOX_MAX_ACTIONS - 5)
+            self._mb_head32, self._mb_tail32 = self._mb_head64.view(np.float32), self._mb_tail64.view(np.float32)
+            self._srv_stream = torch.cuda.Stream(device=self.table.device)
+        self._orders_for_generic()
+        self._srv_stream.wait_stream(torch.cuda.current_stream())  # (everything enqueued so far: sampler reset, env.reset, ...)
+        self._mb.seq_in2 = self._mb.seq_out
+        self._mb.seq_in = self._mb.seq_out  # (nothing pending)
+        L.check(lib.offsim_step_server_start(C.byref(self.table.c), C.byref(self.state.c), self._mb_ptr, mode, self._SERVER_IDLE_POLLS,
+                                             self._srv_stream.cuda_stream))
+        self._srv_mode = mode
+        self._srv_last = (None, None)
+
+    def reset_single(self):
+        """PSRS.reset (psrs.py:32-37) for the R = 1 environment, as a host int (the initial row or -1): served by the resident step
+        server when it is up (no stop / start around an episode end), otherwise offsim_env_reset."""
+        mb = getattr(self, "_mb", None)
+        if self.R == 1 and mb is not None and mb.state in (L.SERVER_STARTING, L.SERVER_RUNNING):
+            return self._server_step(None, self._srv_mode, L.SERVER_CMD_RESET, self.reject_mode)[0]
+        return int(self.reset().cpu()[0])
+
+    def _server_step(self, p_new, mode, cmd, rm):
+        mb = self.__dict__.get("_mb")
+        if mb is None or mb.state not in (L.SERVER_STARTING, L.SERVER_RUNNING) or self._srv_mode != mode:
+            self._quiesce()
+            self._server_start(mode)
+            mb = self._mb
+            self._srv_last = (None, None)
+        if p_new is not None:
+            head, tail = (self._mb_head32, self._mb_tail32) if mode == L.PROB_F32 else (self._mb_head64, self._mb_tail64)
+            p = p_new.reshape(-1)
+            n, nh = len(p), len(head)
+            if n <= nh:
+                head[:n] = p
+            else:
+                head[:] = p[:nh]
+                tail[:n - nh] = p[nh:]
+        if self._srv_last != (cmd, rm):  # (command and reject mode stay in the mailbox between requests)
+            mb.cmd, mb.reject_mode = cmd, rm
+            self._srv_last = (cmd, rm)
+        seq = (mb.seq_in + 1) & 0xFFFFFFFF
+        mb.seq_in2 = seq
+        mb.seq_in = seq  # (behind the payload and seq_in2: x86 stores are not reordered with each other)
+        spins = 0
+        while mb.seq_out != seq:
+            spins += 1
+            if (spins & 1023) == 0 and mb.state == L.SERVER_EXITED and mb.seq_out != seq:
+                # the server ended (idle) between our look at its state and the request: start it again; it serves the pending request
+                self._srv_stream.synchronize()
+                pending = mb.seq_in
+                self._server_start(mode)
+                mb.seq_in2 = pending
+                mb.seq_in = pending
+            if spins > 200_000_000:
+                raise L.OffsimError("the resident step server does not answer")
+        row = mb.row
+        self.last_row = row
+        return row, mb.status, mb.popped
+
+    def _quiesce(self):
+        """Stop the resident step server (if it runs) before anything else reads or writes this environment's state: it owns the
+        rollout's cursor / stream / state rows while it is up."""
+        mb = getattr(self, "_mb", None)
+        if mb is None or mb.state not in (L.SERVER_STARTING, L.SERVER_RUNNING):
+            return
+        mb.cmd = L.SERVER_CMD_EXIT
+        self._srv_last = (None, None)
+        mb.seq_in2 = (mb.seq_in + 1) & 0xFFFFFFFF
+        mb.seq_in = mb.seq_in2
+        self._srv_stream.synchronize()  # (it ends on the command, or has ended by itself)
+        mb.seq_out = mb.seq_in
+        torch.cuda.current_stream().wait_stream(self._srv_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_mb", None) is not None:
+                self._quiesce()
+                L.load().offsim_host_free(self._mb_ptr)
+                self._mb = None
+        except Exception:
+            pass
+
     def set_state(self, slots, mask=None):
+        self._quiesce()
         s = slots.to(device=self.table.device, dtype=torch.int32).contiguous()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         L.check(L.load().offsim_env_set_state(C.byref(self.state.c), L.ptr(s), L.ptr(m), L.stream_ptr()))
@@ -396,6 +499,7 @@ class BatchedPSRS:
         tensors: sum_g, n_ep, steps, cand, n_len, status (+ ep_g, ep_len, trace_row, trace_pop when asked).
         fast=None picks the compiled-policy / LDS-window kernel (offsim_eval_mc_keys) whenever it applies
         (f64 probabilities, default reject rule, <= 256 states); fast=False forces the generic kernel."""
+        self._quiesce()
         t, dev, R = self.table, self.table.device, self.R
         if not isinstance(pi_slots, torch.Tensor):
             pi_slots = torch.from_numpy(np.ascontiguousarray(pi_slots))
@@ -462,6 +566,7 @@ class BatchedPSRS:
         case of psrs.py:158); pi_slots is then only the target policy of expected SARSA.  alpha_ep / epsilon_ep: per-episode
         schedules (psrs.py:128-135); snap_cap > 0: out["q_snap"] [R,snap_cap,n_slots,nA] = Q after every snap_stride-th step
         (save_Q); tie_mt [R,625] int32/uint32: NumPy's MT19937 state per rollout for ties between maxima (advanced in place)."""
+        self._quiesce()
         self._orders_for_generic()
         t, dev, R = self.table, self.table.device, self.R
         pi_d = torch.as_tensor(np.ascontiguousarray(pi_slots), dtype=torch.float64).to(dev).reshape(t.n_slots, t.nA).contiguous()
@@ -604,6 +709,7 @@ class PSRS:
         self._reject_func = reject_func
         self.table = TransitionTable(z, a, r, zn, done, p_log, t0)
         self._env = BatchedPSRS(self.table, 1, L.REJECT_DEFAULT if reject_mode is None else reject_mode)
+        self._fault_check = False
         self.s = None
         self.z = None
         self.reset_sampler()   # psrs.py:13 (unseeded on construction)
@@ -625,7 +731,7 @@ class PSRS:
 
     # -- psrs.py:32-37 (the seed argument is ignored there too) --
     def reset(self, seed=None):
-        row = int(self._env.reset().cpu()[0])
+        row = self._env.reset_single()
         self._check_faults()
         if row < 0:
             self.s = None
@@ -638,7 +744,8 @@ class PSRS:
     def step(self, p_new):
         if isinstance(p_new, torch.Tensor):
             p_new = p_new.detach().cpu().numpy()
-        p_new = np.asarray(p_new)
+        elif not isinstance(p_new, np.ndarray):
+            p_new = np.asarray(p_new)
         z = self.z
         if self._reject_func is None:
             row, status, popped = self._env.step_single(p_new)
@@ -650,11 +757,12 @@ class PSRS:
                 if not self._reject_func(p_new, self._p_of(row), self._a_of(row)):
                     self._env.set_state(torch.tensor([self.table.slot_of(self._zn[row])]))
                     break
-        self._check_faults()
-        if status == L.ST_KEYERROR:
-            raise KeyError(z)
-        if status in (L.ST_EXHAUSTED, L.ST_INACTIVE):
-            return None, None, None, None
+        if self._fault_check:
+            self._check_faults()
+        if status != L.ST_OK:
+            if status == L.ST_KEYERROR:
+                raise KeyError(z)
+            return None, None, None, None  # (ST_EXHAUSTED, ST_INACTIVE)
         self.s = self._next_obs[row]
         self.z = int(self._zn[row])
         return self.s, self._r[row], bool(self._done[row]), {"z": z, "a": self._a_of(row), "p": self._p_of(row)}
@@ -676,6 +784,7 @@ class PSRS:
     # -- public attributes of the reference object, materialised on demand --
     @property
     def rejection_sampling_rng(self):
+        self._env._quiesce()
         st = self._env.state.rng.cpu().numpy().view(np.uint64)[0]
         g = np.random.Generator(np.random.PCG64())
         g.bit_generator.state = {"bit_generator": "PCG64", "state": {"state": (int(st[0]) << 64) | int(st[1]),
@@ -687,6 +796,7 @@ class PSRS:
         s = gen.bit_generator.state
         if s["bit_generator"] != "PCG64":
             raise ValueError("only PCG64 generators (np.random.default_rng) can drive the device stream")
+        self._env._quiesce()
         st, inc = s["state"]["state"], s["state"]["inc"]
         m = (1 << 64) - 1
         w = np.array([st >> 64, st & m, inc >> 64, inc & m], dtype=np.uint64).view(np.int64)
@@ -699,6 +809,7 @@ class PSRS:
         return u
 
     def _orders(self):
+        self._env._quiesce()
         t, st = self.table, self._env.state
         seg = t.seg_off.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         order = t.order.cpu().numpy()
@@ -718,6 +829,7 @@ class PSRS:
 
     @property
     def init_queue(self):
+        self._env._quiesce()
         st, t = self._env.state, self.table
         ip = st.init_perm.cpu().numpy().reshape(-1)[: t.N0] if st.init_perm is not None else np.arange(t.N0)
         rows = t.init_orig.cpu().numpy()[ip]

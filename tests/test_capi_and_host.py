@@ -47,7 +47,7 @@ def test_struct_layout_matches_header(tmp_path):
     import subprocess
     from rl_offline_simulation_amd import _lib
     pairs = {"offsim_table": _lib.Table, "offsim_rollouts": _lib.Rollouts, "offsim_evalmc_out": _lib.EvalMCOut, "offsim_td": _lib.TD,
-             "offsim_streams": _lib.Streams, "offsim_column": _lib.Column}
+             "offsim_streams": _lib.Streams, "offsim_column": _lib.Column, "offsim_step_mailbox": _lib.StepMailbox}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "offsim.h"', "int main(void) {"]
     for c_name, cls in pairs.items():
         lines.append(f'  printf("{c_name} %zu\\n", sizeof({c_name}));')

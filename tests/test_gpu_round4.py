@@ -115,3 +115,62 @@ def test_bench_line_carries_the_extra_configurations(gpu):
     for k in ("C2", "C3"):
         assert cfg[k]["parity_ok"] is True and cfg[k]["value"] > 0 and cfg[k]["scan_s"] > 0 and cfg[k]["kernel"].startswith("k_eval_mc")
     assert out["parity_check"]["ok"]
+
+
+def test_step_server_serves_the_same_steps_as_one_launch_per_call(gpu):
+    """PSRS.step through the resident step server (offsim_step_server_start: one wavefront, mailbox in host-coherent pinned memory)
+    against one offsim_step_batch launch per call: same served rows, rewards, done flags, states and stream positions over whole
+    episodes -- incl. env.reset() at episode ends (the server is stopped and started again around it), a float32 p_new (the other
+    instance of the kernel), the Python-side reject hook (POP_ONE + set_state) and reset_sampler between runs; and against the oracle."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.evaluators import PSRS
+    e = synth.synth_iid(6000, 12, 3, seed=11)
+    t0 = e["steps"] == 0
+    args = (e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    ora = O.OraclePSRS(*args)
+    g = np.random.default_rng(5)
+    ps = g.dirichlet(np.ones(3), size=4000)
+
+    def run(server, p_dtype=np.float64, hook=False, seed=21):
+        prev = os.environ.get("OFFSIM_STEP_SERVER")
+        os.environ["OFFSIM_STEP_SERVER"] = "1" if server else "0"
+        try:
+            kw = {}
+            if hook:
+                kw["reject_func"] = lambda p_new, p_log, a: False  # accept whatever comes (FollowObservationOnly's rule, on the host)
+            env = PSRS.from_arrays(*args, **kw)
+            env.reset_sampler(seed)
+            out, s = [], env.reset()
+            for k in range(len(ps)):
+                r = env.step(ps[k].astype(p_dtype))
+                if r[0] is None:
+                    break
+                out.append((int(env._env.last_row), float(r[1]), bool(r[2]), int(env.z)))
+                if r[2] and env.reset() is None:
+                    break
+            if server and not hook:
+                assert env._env._mb is not None and env._env._mb.state in (L.SERVER_STARTING, L.SERVER_RUNNING, L.SERVER_EXITED)
+            st = env.rejection_sampling_rng.bit_generator.state["state"]["state"]
+            return out, st
+        finally:
+            if prev is None:
+                os.environ.pop("OFFSIM_STEP_SERVER", None)
+            else:
+                os.environ["OFFSIM_STEP_SERVER"] = prev
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert len(a) > 500 and a == b and sa == sb
+    # the oracle on the same seed and distributions
+    ora.reset_sampler(21)
+    ora.reset()
+    for k, (row, r, d, z) in enumerate(a):
+        got, _ = ora.step(ps[k])
+        assert got == row, k
+        if d:
+            ora.reset()
+    for kw in (dict(p_dtype=np.float32), dict(hook=True), dict(seed=22)):
+        x, sx = run(True, **kw)
+        y, sy = run(False, **kw)
+        assert len(x) > 100 and x == y and sx == sy, kw
