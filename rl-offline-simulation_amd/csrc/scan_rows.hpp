@@ -146,13 +146,21 @@ __host__ __device__ constexpr RowsFormat rows_format(int fmt) {  // (the format 
 // bits 16.. of the local row out of a format-B payload (digest or key): bits 8, 9 and 11..15
 __device__ __forceinline__ uint32_t rows_loc_hi(uint32_t pay) { return ((pay >> 8) & 3u) | (((pay >> 11) & 0x1fu) << 2); }
 
+// Cache policy of the reward pipeline's loads (local row of a served candidate, its reward; one dword out of a sector that is not
+// looked at again): NON-TEMPORAL.  With the default policy these 128 B per accepted step pass through L2 and push out the digest
+// sectors the window top-ups and the dry-row reads come back to; measured at 10 M x 4096 (tools/clock_rows.py): the XCDs with the
+// longer memory latency ran at 477 cycles per iteration against 453 on the others and the kernel ends with its slowest workgroup
+// -- with nt all eight run at 457, kernel 1.022 -> 0.990 s.  (nt on the digest requests themselves: 550 cycles per iteration.)
+#ifndef ROWS_RW_CACHE
+#define ROWS_RW_CACHE " nt"
+#endif
 __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst_uniform) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dword %1, off\n\t"
+        "global_load_lds_dword %1, off" ROWS_RW_CACHE "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gptr), "s"(lds_dst_uniform)
@@ -781,6 +789,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
+#ifdef ROWS_HELPER_PRIO_LOW
+            __builtin_amdgcn_s_setprio(ROWS_HELPER_PRIO);
+#endif
 #ifdef ROWS_DIAG_LAG
             lag_d1 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
 #endif
@@ -829,6 +840,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 LV32(dma_a + rq.s + lane * 4u) = q_s;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
+#ifdef ROWS_HELPER_PRIO_LOW  /* (A/B builds: issue priority only for the request round; the reward pipeline, the draws and the polling below it) */
+            __builtin_amdgcn_s_setprio(ROWS_HELPER_PRIO_LOW);
+#endif
 #ifdef ROWS_DIAG_LAG
             {
                 const uint32_t dl = (uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u);
@@ -1304,68 +1318,53 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #else
 #define ROWS_DRY_SECTOR
 #endif
+// The candidates of a dry row.  Default: straight from the stream.  ROWS_DRY_STAGE (experiment, off): first a look into the request
+// areas -- with two ticks between a request round and its landing a top-up of the very window end is often already on chip (54 % of the
+// dry rows at 10 M x 4096) -- under a seqlock on the descriptor.  It bought nothing measurable (the event is ~1500 cycles either way:
+// five dependent LDS round trips against one memory round trip) and one run in ten of tests/test_gpu_round2.py's 2 M x 256 comparison
+// then differed from the window kernel (a race that was not found): not built.
+#ifdef ROWS_DRY_STAGE
+#define ROWS_DRY_CLAIM_READ "ds_read_u8 v107, v107\n\t"
+#define ROWS_DRY_CANDIDATES ROWS_DRY_CANDIDATES_STAGED
+#else
+#define ROWS_DRY_CLAIM_READ
+#define ROWS_DRY_CANDIDATES ROWS_DRY_CANDIDATES_STREAM
+#endif
+#ifdef ROWS_DRY_NO_STAGE  /* (debug build: the request areas are never used by the dry-row path) */
+#define ROWS_DRY_NOSTAGE "s_mov_b64 s[36:37], 0\n\t"
+#else
+#define ROWS_DRY_NOSTAGE
+#endif
 #ifdef ROWS_DRY_COUNT_HITS  /* (debug build: rows served from the request areas counted in bits 16.. of the dry counter) */
 #define ROWS_DRY_HITS "v_mov_b32 v99, 0x10000\n\t" "v_cndmask_b32_e64 v99, 0, v99, s[36:37]\n\t" "v_add_u32 %[ndry], %[ndry], v99\n\t"
 #else
 #define ROWS_DRY_HITS
 #endif
-#define ROWS_DRY_HANDLER                                                                                                     \
-            "51:\n\t"                                                                                                     \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
-            "v_mov_b32 %[ra], %[rb]\n\t"                                                                                  \
-            "v_mov_b32 %[w], %[w2]\n\t"                                                                                   \
-            "v_mov_b32 %[key], %[key2]\n\t"                                                                               \
-            "50:\n\t"                                                                                                     \
-            "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the early read of the next entry is on its way into w2) */ \
-            "v_cmp_eq_u32_e64 s[30:31], -1, %[key]\n\t"                  /* the rows without a clear accept */           \
-            /* may every row that needs one take an initial state?  (a dry row's step may end an episode: asked of all of them) */ \
-            "v_and_b32 v117, 0x400, %[key]\n\t"                                                                           \
-            "v_cmp_ne_u32_e32 vcc, 0, v117\n\t"                                                                           \
-            "v_cmp_eq_u32_e64 s[32:33], 0, %[left]\n\t"                                                                   \
-            "s_and_b64 s[32:33], s[32:33], vcc\n\t"                      /* (the all-ones key carries the done bit: covers the dry rows) */ \
-            "s_cbranch_scc1 2f\n\t"                                                                                       \
-            /* entries the window held: lanes 0..7 (8..15 repeat them) */                                                \
-            "v_cmp_ne_u32_e32 vcc, 0, %[w]\n\t"                                                                           \
-            "v_lshl_add_u32 v123, %[zz], 2, %[landb]\n\t"                /* &land[state] */                              \
-            "v_lshl_add_u32 v126, %[zz], 2, %[sega]\n\t"                 /* &seg_off[state] */                           \
-            "v_cndmask_b32_e64 %[nrd], 0, 1, vcc\n\t"                                                                     \
-            "s_nop 1\n\t"                                                                                                 \
-            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
-            "ds_read_b32 %[e], v123\n\t"                                                                                  \
-            "ds_read2_b32 v[120:121], v126 offset1:1\n\t"                                                                 \
-            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                     \
-            "v_lshrrev_b32 v118, 2, %[li4]\n\t"                          /* lane of the row, 0..15 */                    \
-            "v_add_u32 v119, 4, %[li4]\n\t"                                                                               \
-            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                         \
-            "v_lshlrev_b32 v119, 24, v119\n\t"                           /* (lane + 1) << 26 */                          \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "v_sub_u32 v122, v121, v120\n\t"                             /* rows of the state */                         \
-            "v_sub_u32 v122, v122, %[e]\n\t"                             /* ... still queued behind the window */        \
-            "v_cmp_gt_u32_e32 vcc, 16, v122\n\t"                         /* fewer than sixteen: the C++ path */          \
-            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
-            "s_cbranch_vccnz 2f\n\t"                                                                                      \
-            /* draw counter of the dry rows behind the entries held: c4 - 255 (the all-ones key was added) + 4 hv, as a 16-lane slot */ \
-            "v_add_u32 v127, 0xffffff01, %[c4]\n\t"                                                                       \
-            "v_lshl_add_u32 v127, %[nrd], 2, v127\n\t"                                                                    \
-            "v_sub_u32 v127, v127, v110\n\t"                             /* 4 x draws consumed */                        \
-            "s_sub_u32 s32, 17, %[it]\n\t"                               /* this event's sixteen draws, and eight for every look left in the tick (the loop */ \
-            "s_lshl_b32 s32, s32, 5\n\t"                                 /* itself never checks: a tick's worth is in the ring when it starts): 4 x (16 + 8 (15 - it)) */ \
-            "v_add_u32 v126, s32, v127\n\t"                                                                               \
-            "v_cmp_gt_u32_e32 vcc, v126, %[gen4]\n\t"                    /* ... are not known to be in the ring */     \
-            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
-            "s_cbranch_vccnz 2f\n\t"                                                                                      \
-            "v_add_u32 v127, v127, %[li4]\n\t"                                                                            \
-            "v_and_or_b32 v126, v127, v115, %[ringa]\n\t"                                                                 \
+#define ROWS_DRY_CANDIDATES_STREAM                                                                                            \
+            "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* grouped position of this lane's candidate */ \
+            "v_mov_b32 v125, 0\n\t"                                                                                       \
+            "v_lshl_add_u64 v[124:125], v[124:125], 2, %[dbase]\n\t"                                                      \
+            /* Candidates up to the end of the 64-byte sector the queue's head lies in (the window's last top-up came out of it). */ \
+            "v_lshrrev_b32 v121, 2, v124\n\t"                                                                             \
+            "v_sub_u32 v121, v121, v118\n\t"                                                                              \
+            "v_and_b32 v121, 15, v121\n\t"                                                                                \
+            "v_sub_u32 v121, 16, v121\n\t"                             /* candidates in the sector, 1..16 (the same in every lane of the row) */ \
+            ROWS_DRY_SECTOR                                                                                                \
+            "v_cmp_lt_u32_e32 vcc, v118, v121\n\t"                                                                        \
+            "s_mov_b64 exec, s[30:31]\n\t"                                                                                \
+            "v_mov_b32 %[zn], -1\n\t"                                  /* (a lane without a candidate accepts nothing) */ \
+            "s_and_b64 exec, exec, vcc\n\t"                                                                               \
+            "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
+            "ds_read_b32 v117, v126\n\t"                                 /* draw c + hv + lane */                        \
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+#define ROWS_DRY_CANDIDATES_STAGED                                                                                            \
             /* ---- Is a top-up of this very window end waiting in the request areas?  (Two ticks pass between a request round and  */ \
             /* its landing, ROWS_LAND_LAG: most of that time the digests are already on chip.)  The state's claim byte names, per    */ \
             /* round parity, the lane that made the state's last request; its descriptor says whether it was aimed at the window end */ \
             /* as it stands (= p), the first word of each group of four whether the group has arrived, and a second look at the      */ \
             /* descriptor behind the data whether the helper has recycled the set meanwhile (it clears the descriptors first). */ \
             "v_mbcnt_lo_u32_b32 v108, -1, 0\n\t"                                                                          \
-            "v_add_u32 v107, %[zz], %[claimb]\n\t"                                                                        \
             "v_mbcnt_hi_u32_b32 v108, -1, v108\n\t"                                                                       \
-            "ds_read_u8 v107, v107\n\t"                                                                                   \
             "v_lshlrev_b32 v108, 2, v108\n\t"                                                                             \
             "v_sub_u32 v108, v108, %[li4]\n\t"                           /* 4 x the row's first lane */                  \
             "v_add_u32 v108, %[dmaa], v108\n\t"                                                                           \
@@ -1381,6 +1380,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "ds_read_b32 v101, v106 offset:2304\n\t"                                                                      \
             "ds_read_b32 v102, v107 offset:4608\n\t"                     /* ... of set 1 */                              \
             "ds_read_b32 v103, v107 offset:4864\n\t"                                                                      \
+            "ds_read_b32 v117, v126\n\t"                                 /* (and the draws c + hv + lane: needed last) */ \
             /* (meanwhile) candidates up to the end of the 64-byte sector the queue's head lies in: what the stream read may take */ \
             "v_lshrrev_b32 v121, 2, v124\n\t"                                                                             \
             "v_sub_u32 v121, v121, v118\n\t"                                                                              \
@@ -1433,6 +1433,14 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                  \
             "v_cndmask_b32_e64 v104, 4, 8, s[40:41]\n\t"                 /* staged candidates */                         \
             "s_and_b64 s[36:37], s[36:37], vcc\n\t"                      /* rows served from the request areas */        \
+            ROWS_DRY_NOSTAGE                                                                                               \
+            /* (a group of four is one load, but its dwords need not appear at once: every staged candidate that counts must be there --   \
+               a lane that still sees the mark sends ALL rows of this event to the stream, which is rare) */                 \
+            "v_cmp_lt_u32_e64 s[38:39], v118, v104\n\t"                  /* lanes with a staged candidate */             \
+            "v_cmp_eq_u32_e32 vcc, -1, v101\n\t"                                                                          \
+            "s_and_b64 s[38:39], s[38:39], s[36:37]\n\t"                                                                  \
+            "s_and_b64 vcc, vcc, s[38:39]\n\t"                                                                            \
+            "s_cselect_b64 s[36:37], 0, s[36:37]\n\t"                                                                     \
             "s_nop 0\n\t"                                                                                                 \
             "v_cndmask_b32_e64 v121, v121, v104, s[36:37]\n\t"           /* candidates at hand: the staged ones, or the sector's */ \
             "v_cmp_lt_u32_e32 vcc, v118, v121\n\t"                                                                        \
@@ -1443,10 +1451,60 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_andn2_b64 exec, exec, s[36:37]\n\t"                       /* the other rows read the stream */            \
             "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
             "s_mov_b64 exec, s[38:39]\n\t"                                                                                \
-            "ds_read_b32 v117, v126\n\t"                                 /* draw c + hv + lane */                        \
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                           \
             "v_cndmask_b32_e64 %[w2], %[w2], v101, s[36:37]\n\t"                                                          \
-            ROWS_DRY_HITS                                                                                                  \
+            ROWS_DRY_HITS
+#define ROWS_DRY_HANDLER                                                                                                     \
+            "51:\n\t"                                                                                                     \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
+            "v_mov_b32 %[ra], %[rb]\n\t"                                                                                  \
+            "v_mov_b32 %[w], %[w2]\n\t"                                                                                   \
+            "v_mov_b32 %[key], %[key2]\n\t"                                                                               \
+            "50:\n\t"                                                                                                     \
+            "s_waitcnt lgkmcnt(0)\n\t"                                   /* (the early read of the next entry is on its way into w2) */ \
+            "v_cmp_eq_u32_e64 s[30:31], -1, %[key]\n\t"                  /* the rows without a clear accept */           \
+            /* may every row that needs one take an initial state?  (a dry row's step may end an episode: asked of all of them) */ \
+            "v_and_b32 v117, 0x400, %[key]\n\t"                                                                           \
+            "v_cmp_ne_u32_e32 vcc, 0, v117\n\t"                                                                           \
+            "v_cmp_eq_u32_e64 s[32:33], 0, %[left]\n\t"                                                                   \
+            "s_and_b64 s[32:33], s[32:33], vcc\n\t"                      /* (the all-ones key carries the done bit: covers the dry rows) */ \
+            "s_cbranch_scc1 2f\n\t"                                                                                       \
+            /* entries the window held: lanes 0..7 (8..15 repeat them) */                                                \
+            "v_cmp_ne_u32_e32 vcc, 0, %[w]\n\t"                                                                           \
+            "v_lshl_add_u32 v123, %[zz], 2, %[landb]\n\t"                /* &land[state] */                              \
+            "v_lshl_add_u32 v126, %[zz], 2, %[sega]\n\t"                 /* &seg_off[state] */                           \
+            "v_cndmask_b32_e64 %[nrd], 0, 1, vcc\n\t"                                                                     \
+            "s_nop 1\n\t"                                                                                                 \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+            "v_add_u32 v107, %[zz], %[claimb]\n\t"                                                                        \
+            "ds_read_b32 %[e], v123\n\t"                                                                                  \
+            "ds_read2_b32 v[120:121], v126 offset1:1\n\t"                                                                 \
+            ROWS_DRY_CLAIM_READ                                                                                            \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                     \
+            "v_lshrrev_b32 v118, 2, %[li4]\n\t"                          /* lane of the row, 0..15 */                    \
+            "v_add_u32 v119, 4, %[li4]\n\t"                                                                               \
+            "v_add_u32_dpp %[nrd], %[nrd], %[nrd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                         \
+            "v_lshlrev_b32 v119, 24, v119\n\t"                           /* (lane + 1) << 26 */                          \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+            "v_sub_u32 v122, v121, v120\n\t"                             /* rows of the state */                         \
+            "v_sub_u32 v122, v122, %[e]\n\t"                             /* ... still queued behind the window */        \
+            "v_cmp_gt_u32_e32 vcc, 16, v122\n\t"                         /* fewer than sixteen: the C++ path */          \
+            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
+            "s_cbranch_vccnz 2f\n\t"                                                                                      \
+            /* draw counter of the dry rows behind the entries held: c4 - 255 (the all-ones key was added) + 4 hv, as a 16-lane slot */ \
+            "v_add_u32 v127, 0xffffff01, %[c4]\n\t"                                                                       \
+            "v_lshl_add_u32 v127, %[nrd], 2, v127\n\t"                                                                    \
+            "v_sub_u32 v127, v127, v110\n\t"                             /* 4 x draws consumed */                        \
+            "s_sub_u32 s32, 17, %[it]\n\t"                               /* this event's sixteen draws, and eight for every look left in the tick (the loop */ \
+            "s_lshl_b32 s32, s32, 5\n\t"                                 /* itself never checks: a tick's worth is in the ring when it starts): 4 x (16 + 8 (15 - it)) */ \
+            "v_add_u32 v126, s32, v127\n\t"                                                                               \
+            "v_cmp_gt_u32_e32 vcc, v126, %[gen4]\n\t"                    /* ... are not known to be in the ring */     \
+            "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
+            "s_cbranch_vccnz 2f\n\t"                                                                                      \
+            "v_add_u32 v127, v127, %[li4]\n\t"                                                                            \
+            "v_and_or_b32 v126, v127, v115, %[ringa]\n\t"                                                                 \
+            ROWS_DRY_CANDIDATES                                                                                            \
             "v_cmp_lt_u32_e32 vcc, 0x8000, %[w2]\n\t"                    /* the window's bias (rows_bias) */             \
             "v_add_u32 v122, 0xffff8000, %[w2]\n\t"                                                                       \
             "v_mov_b32 v125, 0x200\n\t"                                  /* ROWS_NEVER (a literal and vcc do not share the constant bus) */ \
