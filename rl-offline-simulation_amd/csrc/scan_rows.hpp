@@ -1700,7 +1700,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         if constexpr (fmt_b) {
             ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
         } else {
-#if defined(ROWS_NO_DRY_ASM) || ROWS_LAND_LAG != 2  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
+#if defined(ROWS_NO_DRY_ASM) || (defined(ROWS_DRY_STAGE) && ROWS_LAND_LAG != 2)  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "6", "");
 #else
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER);

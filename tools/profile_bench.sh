@@ -9,7 +9,7 @@ shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-parity-check $*"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-parity-check --no-configs $*"
 DIGEST=$(python3 $GRAFT_REPO_ROOT/bench.py --print-csrc-digest)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
