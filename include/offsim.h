@@ -196,6 +196,13 @@ int offsim_host_alloc(int64_t bytes, void **host_ptr);
 int offsim_host_free(void *host_ptr);
 int offsim_step_server_start(const offsim_table *t, offsim_rollouts *ro, offsim_step_mailbox *mailbox, int32_t prob_mode,
                              uint32_t idle_polls, void *stream);
+/* The host side of ONE request, in C (no device call: stores to the mailbox, then a spin on seq_out): p_new = n_actions probabilities
+ * (f64 / f32 by prob_mode; NULL for RESET), out3 = {row, status, popped}.  Returns OFFSIM_OK, or OFFSIM_SERVER_GONE (> 0) when the
+ * server ended by itself before it saw the request -- the request stays posted: synchronise the server's stream, start it again (it
+ * serves the posted request) and wait for seq_out == seq_in -- or OFFSIM_EHIP after max_spins polls (0: no bound). */
+#define OFFSIM_SERVER_GONE 1
+int offsim_step_server_call(offsim_step_mailbox *mailbox, const void *p_new, int32_t n_actions, int32_t prob_mode, uint32_t cmd,
+                            int32_t reject_mode, uint64_t max_spins, int32_t *out3);
 
 /* Sets the current state of masked rollouts (used after a Python-side accept): cur_slot[r] = slot[r]. */
 int offsim_env_set_state(offsim_rollouts *ro, const int32_t *slot, const uint8_t *mask, void *stream);

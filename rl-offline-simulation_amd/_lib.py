@@ -61,6 +61,7 @@ class TD(C.Structure):
 MAILBOX_MAX_ACTIONS = 24
 SERVER_CMD_STEP, SERVER_CMD_POP_ONE, SERVER_CMD_EXIT, SERVER_CMD_RESET = 1, 2, 3, 4
 SERVER_STARTING, SERVER_RUNNING, SERVER_EXITED = 1, 2, 3
+SERVER_GONE = 1  # offsim_step_server_call: the server ended before it saw the request
 
 
 class StepMailbox(C.Structure):
@@ -110,6 +111,7 @@ SIGNATURES = {
     "offsim_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
     "offsim_host_free": (C.c_int, [_vp]),
     "offsim_step_server_start": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_uint32, _vp]),
+    "offsim_step_server_call": (C.c_int, [_vp, _vp, _i32, _i32, C.c_uint32, _i32, C.c_uint64, _vp]),
     "offsim_async_faults": (C.c_int, []),
     "offsim_encode_box": (C.c_int, [_vp, _i64, _vp, _vp]),
     "offsim_encode_mlp": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),

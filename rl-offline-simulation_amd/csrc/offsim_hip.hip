@@ -663,7 +663,8 @@ template <typename PL, typename PROB>
 __device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uint32_t *__restrict__ seg_off,
                                                  const uint32_t *__restrict__ perm_row, int slot, uint32_t *cursor,
                                                  const PROB *pnew, int reject_mode, uint32_t max_pop, WaveRng &rng,
-                                                 uint64_t &consumed) {
+                                                 uint64_t &consumed, uint32_t width = WAVE) {
+    // (width: candidates looked at per round -- the step server looks at the few whose lines it has touched ahead of the request)
     const int lane = threadIdx.x & (WAVE - 1);
     StepResult res;
     res.popped = 0;
@@ -690,7 +691,7 @@ __device__ __forceinline__ StepResult psrs_step(const offsim_table &t, const uin
             res.status = OFFSIM_ST_EXHAUSTED;
             break;
         }
-        uint32_t nv = rem < WAVE ? rem : WAVE;
+        uint32_t nv = rem < width ? rem : width;
         if (reject_mode == OFFSIM_REJECT_NEVER) nv = 1;
         if (max_pop && nv > max_pop - res.popped) nv = max_pop - res.popped;
         const bool valid = (uint32_t)lane < nv;
@@ -1096,6 +1097,27 @@ __device__ __forceinline__ T sys_load(const T *p) { return __hip_atomic_load(p, 
 template <typename T>
 __device__ __forceinline__ void sys_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// The lines the next step of state `slot` will read -- segment bounds, cursor, the order entries and table rows of its next `width`
+// candidates -- touched while the server has nothing to do: the request then finds them in the CU's vector cache / L2 instead of
+// walking four dependent trips to memory (~0.7 us each, tools/micro/memlat.hip).  Values are not kept: the step reads them again.
+#define SERVER_LOOK 8u
+template <typename PL>
+__device__ __forceinline__ void server_touch_ahead(const offsim_table &t, const uint32_t *__restrict__ perm_row, int slot, const uint32_t *cursor) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (slot < 0 || slot >= t.n_slots) return;
+    const uint32_t beg = t.seg_off[slot], len = t.seg_off[slot + 1] - beg, cur = cursor[slot];
+    if (cur >= len) return;
+    const uint32_t rem = len - cur, nv = rem < SERVER_LOOK ? rem : SERVER_LOOK;
+    uint32_t g = beg + cur + ((uint32_t)lane < nv ? lane : 0);
+    if (perm_row) g = perm_row[g];
+    const PL *plog = (const PL *)t.p_log;
+    uint32_t x = (uint32_t)t.a[g] + (uint32_t)t.z_next[g] + t.done[g] + (uint32_t)t.orig_idx[g];
+    x += t.r_dtype == OFFSIM_F64 ? ((const uint32_t *)t.r)[2 * (int64_t)g] : ((const uint32_t *)t.r)[g];
+    const unsigned char *row = (const unsigned char *)(plog + (int64_t)g * t.nA);
+    x += row[0] + row[(int64_t)t.nA * sizeof(PL) - 1];  // (a row of <= 24 probabilities spans two lines at most)
+    asm volatile("" ::"v"(x));
+}
+
 template <typename PL, typename PROB>
 __global__ void __launch_bounds__(64) k_step_server(offsim_table t, offsim_rollouts ro, offsim_step_mailbox *mb, uint32_t idle_polls) {
     __shared__ Jump table[WAVE + 1];
@@ -1109,18 +1131,41 @@ __global__ void __launch_bounds__(64) k_step_server(offsim_table t, offsim_rollo
     U128 base = u128(ro.rng[0], ro.rng[1]);
     const U128 inc = u128(ro.rng[2], ro.rng[3]);
     const uint32_t *head = (const uint32_t *)mb;
+    const bool pcg = ro.rng_kind != OFFSIM_STREAM_PHILOX;
+    if (pcg) {  // the jump table depends on the stream's increment only: built once, not per request
+        table[lane + 1] = pcg_jump(inc, (uint64_t)lane + 1);
+        if (lane == 0) {
+            Jump id;
+            id.mult = u128(0, 1);
+            id.plus = u128(0, 0);
+            table[0] = id;
+        }
+    }
+    server_touch_ahead<PL>(t, ro.perm, slot, ro.cursor);
     for (;;) {
         // One poll = ONE read of the mailbox's first 64 bytes (lane i: dword i): request number, command, reject mode, the first
         // probabilities, and the request number once more in the line's last dword -- the host writes that one before the first, so a
         // snapshot that shows both holds the payload between them, whatever order its halves were read in.
+        // FOUR polls are in flight (loads return in order): a request is seen a quarter of a PCIe read after it is posted, on average,
+        // instead of half of one.
         uint32_t seq = last, polls = 0, w = 0;
+#define SERVER_POLL() (lane < 16 ? sys_load(head + lane) : 0u)
+        uint32_t w0 = SERVER_POLL(), w1 = SERVER_POLL(), w2 = SERVER_POLL(), w3 = SERVER_POLL();
+#define SERVER_CHECK(wk)                                                                                                  \
+    {                                                                                                                     \
+        w = wk;                                                                                                           \
+        seq = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);                                                             \
+        if ((seq != last && (uint32_t)__builtin_amdgcn_readlane((int)w, 15) == seq) || ++polls > idle_polls) break;       \
+        wk = SERVER_POLL();                                                                                               \
+    }
         for (;;) {
-            w = lane < 16 ? sys_load(head + lane) : 0u;
-            seq = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
-            if (seq != last && (uint32_t)__builtin_amdgcn_readlane((int)w, 15) == seq) break;
-            if (++polls > idle_polls) break;
-            __builtin_amdgcn_s_sleep(1);
+            SERVER_CHECK(w0)
+            SERVER_CHECK(w1)
+            SERVER_CHECK(w2)
+            SERVER_CHECK(w3)
         }
+#undef SERVER_CHECK
+#undef SERVER_POLL
         if (seq == last || (uint32_t)__builtin_amdgcn_readlane((int)w, 15) != seq) break;  // idle: end (the host starts the server again with its next request)
         const uint32_t cmd = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
         const int reject_mode = __builtin_amdgcn_readlane((int)w, 2);
@@ -1160,14 +1205,17 @@ __global__ void __launch_bounds__(64) k_step_server(offsim_table t, offsim_rollo
             if (slot >= 0) {
                 WaveRng rng;
                 rng.kind = ro.rng_kind;
-                if (reject_mode != OFFSIM_REJECT_NEVER) wave_rng_init(rng, table, base, inc, ro.rng_kind);
+                rng.table = table;
+                rng.seed = base.hi;  // (as wave_rng_init, without filling the table again)
+                rng.c = base.lo;
+                if (pcg) rng.lane_state = pcg_apply(table[lane + 1], base);
                 uint64_t consumed = 0;
-                const StepResult s = psrs_step<PL, PROB>(t, t.seg_off, ro.perm, slot, ro.cursor, p_sh, reject_mode, max_pop, rng, consumed);
-                if (consumed && ro.rng_kind == OFFSIM_STREAM_PHILOX) {
+                const StepResult s = psrs_step<PL, PROB>(t, t.seg_off, ro.perm, slot, ro.cursor, p_sh, reject_mode, max_pop, rng, consumed, SERVER_LOOK);
+                if (consumed && !pcg) {
                     base.lo += consumed;
                     if (lane == 0) ro.rng[1] = base.lo;
                 } else if (consumed) {
-                    base = pcg_apply(pcg_jump(inc, consumed), base);
+                    base = pcg_apply(consumed <= WAVE ? table[consumed] : pcg_jump(inc, consumed), base);
                     if (lane == 0) {
                         ro.rng[0] = base.hi;
                         ro.rng[1] = base.lo;
@@ -1187,6 +1235,7 @@ __global__ void __launch_bounds__(64) k_step_server(offsim_table t, offsim_rollo
             const u32x4 ans = {seq, (uint32_t)row, (uint32_t)status, popped};
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&mb->seq_out), "v"(ans) : "memory");
         }
+        server_touch_ahead<PL>(t, ro.perm, slot, ro.cursor);  // (behind the answer: the caller is busy with it for a few microseconds)
         last = seq;
     }
     __threadfence_system();
@@ -1204,6 +1253,36 @@ extern "C" int offsim_host_alloc(int64_t bytes, void **host_ptr) {
 
 extern "C" int offsim_host_free(void *host_ptr) {
     if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return OFFSIM_OK;
+}
+
+// Host side of one request to the resident step server (the protocol of include/offsim.h, in C: a Python caller pays one foreign
+// call per PSRS.step instead of a dozen attribute stores and a polling loop in the interpreter).
+extern "C" int offsim_step_server_call(offsim_step_mailbox *mb, const void *p_new, int32_t n_actions, int32_t prob_mode, uint32_t cmd,
+                                       int32_t reject_mode, uint64_t max_spins, int32_t *out3) {
+    if (!mb || !out3 || n_actions < 0 || n_actions > OFFSIM_MAILBOX_MAX_ACTIONS) return fail(OFFSIM_EINVAL, "step_server_call: bad argument%s");
+    volatile offsim_step_mailbox *m = mb;
+    if (p_new && n_actions > 0) {
+        const size_t item = prob_mode == OFFSIM_PROB_F32 ? 4 : 8, head_bytes = sizeof(mb->p_head), total = item * (size_t)n_actions;
+        memcpy((void *)mb->p_head, p_new, total < head_bytes ? total : head_bytes);
+        if (total > head_bytes) memcpy((void *)mb->p_tail, (const char *)p_new + head_bytes, total - head_bytes);
+    }
+    if (m->cmd != cmd) m->cmd = cmd;
+    if (m->reject_mode != reject_mode) m->reject_mode = reject_mode;
+    const uint32_t seq = m->seq_in + 1u;
+    __atomic_store_n(&mb->seq_in2, seq, __ATOMIC_RELEASE);  // behind the payload
+    __atomic_store_n(&mb->seq_in, seq, __ATOMIC_RELEASE);   // ... and last
+    uint64_t spins = 0;
+    while (__atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 1023u) == 0) {
+            if (m->state == OFFSIM_SERVER_EXITED && __atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) return OFFSIM_SERVER_GONE;
+            if (max_spins && spins > max_spins) return fail(OFFSIM_EHIP, "step_server_call: the resident step server does not answer%s");
+        }
+    }
+    out3[0] = m->row;
+    out3[1] = m->status;
+    out3[2] = (int32_t)m->popped;
     return OFFSIM_OK;
 }
 

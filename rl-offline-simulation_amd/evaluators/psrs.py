@@ -375,7 +375,10 @@ class BatchedPSRS:
         p_new = np.asarray(p_new)
         mode = _prob_mode(t, p_new.dtype)
         rm = self.reject_mode if reject_mode is None else reject_mode
-        if self.R == 1 and t.nA <= L.MAILBOX_MAX_ACTIONS and os.environ.get("OFFSIM_STEP_SERVER", "1") != "0" and (advance or rm == L.REJECT_NEVER):
+        srv = self.__dict__.get("_srv_enabled")
+        if srv is None:  # (looked up once per environment)
+            srv = self._srv_enabled = self.R == 1 and t.nA <= L.MAILBOX_MAX_ACTIONS and os.environ.get("OFFSIM_STEP_SERVER", "1") != "0"
+        if srv and (advance or rm == L.REJECT_NEVER):
             return self._server_step(p_new, mode, L.SERVER_CMD_STEP if advance else L.SERVER_CMD_POP_ONE, rm)
         self._quiesce()
         self._orders_for_generic()
@@ -408,6 +411,11 @@ class BatchedPSRS:
             view = lambda f, n: np.ctypeslib.as_array((C.c_double * n).from_address(ptr.value + getattr(L.StepMailbox, f).offset))
             self._mb_head64, self._mb_tail64 = view("p_head", 5), view("p_tail", L.MAILBOX_MAX_ACTIONS - 5)
             self._mb_head32, self._mb_tail32 = self._mb_head64.view(np.float32), self._mb_tail64.view(np.float32)
+            self._srv_p = np.zeros(L.MAILBOX_MAX_ACTIONS, np.float64)  # staging of p_new at a fixed address (f32: the same bytes, packed)
+            self._srv_p32, self._srv_p_addr = self._srv_p.view(np.float32), self._srv_p.ctypes.data
+            self._srv_out = (C.c_int32 * 3)()
+            self._srv_out_addr = C.addressof(self._srv_out)
+            self._srv_call = lib.offsim_step_server_call
             self._srv_stream = torch.cuda.Stream(device=self.table.device)
         self._orders_for_generic()
         self._srv_stream.wait_stream(torch.cuda.current_stream())  # (everything enqueued so far: sampler reset, env.reset, ...)
@@ -433,31 +441,27 @@ class BatchedPSRS:
             self._server_start(mode)
             mb = self._mb
             self._srv_last = (None, None)
+        # the request itself -- payload, command, the two sequence words, the spin on the answer -- is ONE foreign call
+        n = 0
         if p_new is not None:
-            head, tail = (self._mb_head32, self._mb_tail32) if mode == L.PROB_F32 else (self._mb_head64, self._mb_tail64)
-            p = p_new.reshape(-1)
-            n, nh = len(p), len(head)
-            if n <= nh:
-                head[:n] = p
-            else:
-                head[:] = p[:nh]
-                tail[:n - nh] = p[nh:]
-        if self._srv_last != (cmd, rm):  # (command and reject mode stay in the mailbox between requests)
-            mb.cmd, mb.reject_mode = cmd, rm
-            self._srv_last = (cmd, rm)
-        seq = (mb.seq_in + 1) & 0xFFFFFFFF
+            n = p_new.size
+            (self._srv_p32 if mode == L.PROB_F32 else self._srv_p)[:n] = p_new.reshape(-1)
+        rc = self._srv_call(self._mb_ptr, self._srv_p_addr if n else None, n, mode, cmd, rm, 2_000_000_000, self._srv_out_addr)
+        if rc == 0:
+            out = self._srv_out
+            self.last_row = out[0]
+            return out[0], out[1], out[2]
+        if rc != L.SERVER_GONE:
+            L.check(rc)
+        # the server ended (idle) between our look at its state and the request, which stays posted: start it again; it serves it
+        seq = mb.seq_in
+        self._srv_stream.synchronize()
+        self._server_start(mode)
         mb.seq_in2 = seq
-        mb.seq_in = seq  # (behind the payload and seq_in2: x86 stores are not reordered with each other)
+        mb.seq_in = seq
         spins = 0
         while mb.seq_out != seq:
             spins += 1
-            if (spins & 1023) == 0 and mb.state == L.SERVER_EXITED and mb.seq_out != seq:
-                # the server ended (idle) between our look at its state and the request: start it again; it serves the pending request
-                self._srv_stream.synchronize()
-                pending = mb.seq_in
-                self._server_start(mode)
-                mb.seq_in2 = pending
-                mb.seq_in = pending
             if spins > 200_000_000:
                 raise L.OffsimError("the resident step server does not answer")
         row = mb.row
