@@ -361,13 +361,17 @@ int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
  * per-rollout permutation moves a 64-byte sector per 4-byte digest, so the sampler reset can instead lay the queue
  * orders out as two streams per rollout, both indexed like `perm` (seg_off[s] + k = k-th element of state s's queue):
  *   dig [n, N] u32   digest of the candidate at that queue position      -> read sequentially by the scan
- *   loc [n, N] u16   its row inside the state's segment (grouped row - seg_off[s]), low 16 bits
- * 4 + 2 bytes per queue position and rollout in either of two layouts of the digest (offsim_streams.format):
+ *   loc [n, N] u16   its row inside the state's segment (grouped row - seg_off[s]), low 16 bits (format C: u8, low 8 bits)
+ * 4 + 2 bytes per queue position and rollout (format C: 4 + 1) in one of three layouts of the digest (offsim_streams.format):
  *   OFFSIM_STREAMS_A   [T >> 32 : 21 | done : 1 | z_next : 10] = the high dword of the compiled key; loc is the whole local row:
  *                      every state has at most 65536 rows;
  *   OFFSIM_STREAMS_B   [T >> 37 : 16 | hi[6:2] : 5 | done : 1 | hi[1:0] : 2 | z_next : 8], hi = bits 16..22 of the local row:
  *                      states of up to 2^23 rows, at most 256 states.  (The coarser threshold only widens the band of draws that
  *                      are decided by the exact 53-bit look; results are the same bit for bit.)
+ *   OFFSIM_STREAMS_C   [T >> 39 : 14 | hi[8:2] : 7 | done : 1 | hi[1:0] : 2 | z_next : 8], hi = bits 8..16 of the local row, loc = its
+ *                      low byte: 5 bytes per queue position for states of up to 2^17 rows, at most 255 states -- a sixth less to keep
+ *                      resident and to write per sampler reset (a 12.5 M-row shard x 4096 rollouts: 256 GB instead of 307 GB, one
+ *                      resident tile instead of two).  Written by offsim_shuffle_queues_keys_ws only (every chain chunk by chunk).
  * offsim_compile_digests: dig32[g] = the digest of grouped row g in `format`, local-row bits zero (from offsim_compile_policy's keys).
  * offsim_shuffle_queues_keys: PSRS.reset_sampler's shuffles (psrs.py:22-23,29-30; same orders as offsim_shuffle_queues,
  *   bit for bit) written as those streams; init_perm_out as in offsim_shuffle_queues.  States of more than 65536 rows need
@@ -380,16 +384,17 @@ int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
  *   n_slots <= 256; offsim_table.max_seg must be set: <= 65536 for format A, <= 2^23 for format B (OFFSIM_EUNSUPPORTED otherwise). */
 #define OFFSIM_STREAMS_A 0
 #define OFFSIM_STREAMS_B 1
+#define OFFSIM_STREAMS_C 2
 typedef struct offsim_streams {
     const uint32_t *dig;
     int64_t dig_stride;
-    const uint16_t *loc;
-    int64_t loc_stride;
+    const void *loc;    /* u16 elements (formats A, B) or u8 (format C) */
+    int64_t loc_stride; /* in elements */
     int32_t format; /* OFFSIM_STREAMS_* */
 } offsim_streams;
 int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, int32_t format, uint32_t *dig32_out, void *stream);
 int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
-                               uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream);
+                               uint32_t *dig_out, void *loc_out, uint32_t *init_perm_out, void *stream);
 /* The same with a workspace lent by the caller (device memory, 8-byte aligned, contents irrelevant before and after): the states of
  * more than 65536 rows are then shuffled chunk by chunk in LDS with sequential global traffic only (csrc/shuffle_chunk.hpp) instead
  * of in place with a random line per swap.  offsim_shuffle_workspace_bytes(t, n) = the bytes n persistent workgroups use (one per
@@ -401,7 +406,7 @@ int64_t offsim_shuffle_workspace_bytes(const offsim_table *t, int32_t n_workgrou
 int offsim_shuffle_queues_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
                              void *workspace, int64_t workspace_bytes, void *stream);
 int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
-                                  uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
+                                  uint32_t *dig_out, void *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
                                   void *stream);
 int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro, const offsim_streams *sm, const uint64_t *keys,
                            double gamma, const double *gamma_pow, int64_t n_gamma_pow, int64_t max_episodes,

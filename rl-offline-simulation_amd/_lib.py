@@ -14,7 +14,7 @@ OK = 0
 F32, F64, F16 = 0, 1, 2
 REJECT_DEFAULT, REJECT_NEVER = 0, 1
 STREAM_PCG64, STREAM_PHILOX = 0, 1
-STREAMS_A, STREAMS_B = 0, 1
+STREAMS_A, STREAMS_B, STREAMS_C = 0, 1, 2
 PROB_F64, PROB_F32 = 0, 1
 ST_OK, ST_EXHAUSTED, ST_NO_INIT, ST_KEYERROR, ST_INACTIVE, ST_PROTOCOL = 0, 1, 2, 3, 4, 5
 

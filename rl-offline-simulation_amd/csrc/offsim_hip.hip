@@ -419,9 +419,10 @@ static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspac
     return p;
 }
 static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, uint32_t *dig_out,
-                      uint16_t *loc_out, uint32_t *init_perm_out, uint32_t *perm_out, void *workspace, hipStream_t st) {
+                      void *loc_out, uint32_t *init_perm_out, uint32_t *perm_out, void *workspace, hipStream_t st, uint32_t loc_bits = 16u,
+                      uint32_t chains_above = SHUF_CAP16) {
     uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of long chains, [64 ..] their indices, longest first
-    hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), SHUF_CAP16,
+    hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), chains_above,
                        hdr + 64, hdr + 1, hdr);
     LAUNCH_CHECK();
 #define SHC_LAUNCH_(CB, RG, SQ, PL)                                                                                                     \
@@ -429,7 +430,7 @@ static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *s
         HIP_TRY(allow_big_lds((k_shuffle_chunked<CB, RG, SQ, PL>), 160 * 1024));                                                         \
         hipLaunchKernelGGL((k_shuffle_chunked<CB, RG, SQ, PL>), dim3((unsigned)p.n_wg), dim3(256), p.lds_b, st, t->seg_off, t->N, seeds, n_perm,  \
                            hdr + 64, hdr + 1, hdr, (uint64_t *)((char *)workspace + SHC_HEADER_BYTES), p.words, p.msg_cap, p.kcap, dig32,   \
-                           dig_out, loc_out, t->n_slots, t->N0, init_perm_out, perm_out, p.lc_words);                                   \
+                           dig_out, loc_out, t->n_slots, t->N0, init_perm_out, perm_out, p.lc_words, loc_bits);                         \
     } while (0)
 #define SHC_LAUNCH(CB, RG, SQ)                                                                                                          \
     do {                                                                                                                                \
@@ -457,13 +458,25 @@ extern "C" int offsim_shuffle_queues_ws(const offsim_table *t, const uint64_t *s
 }
 
 extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
-                                             uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
+                                             uint32_t *dig_out, void *loc_out, uint32_t *init_perm_out, void *workspace, int64_t workspace_bytes,
                                              void *stream) {
     if (!t || !seeds || n_perm < 0 || !init_perm_out || (t->N > 0 && (!dig32 || !dig_out || !loc_out)))
         return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad argument%s");
-    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad format%s");
+    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B && format != OFFSIM_STREAMS_C) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: bad format%s");
     if (t->max_seg <= 0 && t->N > 0) return fail(OFFSIM_EINVAL, "shuffle_queues_keys: offsim_table.max_seg must be set%s");
     const bool big = t->max_seg > (int64_t)SHUF_CAP16;
+    if (format == OFFSIM_STREAMS_C) {
+        // one byte of the local row beside the digest: every chain runs on the chunked kernel (the LDS-resident kernel hands its low
+        // positions from launch to launch as 16-bit rows in the loc stream; these streams have no room for them)
+        if (t->max_seg > (1ll << 17) || t->n_slots > 255 || t->N0 > (1ll << 23))
+            return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format C holds 2^17 rows per state, 255 states%s");
+        if (n_perm == 0 || t->N == 0) return OFFSIM_OK;
+        offsim_table tc = *t;  // (the pools are sized for the longest chain, whatever its length)
+        if (tc.max_seg <= (int64_t)SHUF_CAP16) tc.max_seg = (int64_t)SHUF_CAP16 + 1;
+        const ShcPlan pc = shc_plan(&tc, workspace, workspace_bytes, false);
+        if (pc.n_wg < 1) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format C needs a workspace (offsim_shuffle_workspace_bytes)%s");
+        return shc_launch(pc, &tc, seeds, n_perm, dig32, dig_out, loc_out, init_perm_out, nullptr, workspace, (hipStream_t)stream, 8u, 0u);
+    }
     if (big && format != OFFSIM_STREAMS_B)
         return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows: stream format B (or offsim_shuffle_queues)%s");
     if (big && (t->max_seg > (1ll << 23) || t->n_slots > 256)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 256 states%s");
@@ -473,20 +486,20 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     // otherwise in place in global memory (a state: in its slice of dig_out) and one more pass that turns the order into streams
     const ShcPlan p = shc_plan(t, workspace, workspace_bytes, false);
     const bool chunked = p.n_wg >= 1;
-    int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, loc_out, st, chunked);
+    int rc = launch_shuffle(t, seeds, n_perm, big && !chunked ? dig_out : nullptr, init_perm_out, dig32, dig_out, (uint16_t *)loc_out, st, chunked);
     if (rc || (!big && !chunked)) return rc;
     if (chunked) return shc_launch(p, t, seeds, n_perm, dig32, dig_out, loc_out, init_perm_out, nullptr, workspace, st);
     for (int32_t r0 = 0; r0 < n_perm; r0 += 65535) {  // (gridDim.z holds at most 65535 orders)
         const int32_t nz = n_perm - r0 < 65535 ? n_perm - r0 : 65535;
         hipLaunchKernelGGL(k_big_keys, dim3((unsigned)((t->max_seg + 1023) / 1024), (unsigned)t->n_slots, (unsigned)nz), dim3(256), 0, st,
-                           t->seg_off, t->N, dig32, dig_out, loc_out, (uint32_t)r0);
+                           t->seg_off, t->N, dig32, dig_out, (uint16_t *)loc_out, (uint32_t)r0);
         LAUNCH_CHECK();
     }
     return OFFSIM_OK;
 }
 
 extern "C" int offsim_shuffle_queues_keys(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, int32_t format,
-                                          uint32_t *dig_out, uint16_t *loc_out, uint32_t *init_perm_out, void *stream) {
+                                          uint32_t *dig_out, void *loc_out, uint32_t *init_perm_out, void *stream) {
     return offsim_shuffle_queues_keys_ws(t, seeds, n_perm, dig32, format, dig_out, loc_out, init_perm_out, nullptr, 0, stream);
 }
 
@@ -1692,15 +1705,17 @@ __global__ void k_key_digests(const uint64_t *__restrict__ keys, int64_t N, int 
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     const uint32_t hi = (uint32_t)(keys[g] >> 32);  // [T >> 32 : 21 | done | z_next : 10]
-    out[g] = format == OFFSIM_STREAMS_B ? ((hi >> 16) << 16) | (hi & 0x400u) | (hi & 0xffu) : hi;
+    const uint32_t ts = format == OFFSIM_STREAMS_B ? 16u : 18u;  // (formats B, C: a coarser threshold, the local row's upper bits left zero here)
+    out[g] = format == OFFSIM_STREAMS_A ? hi : ((hi >> ts) << ts) | (hi & 0x400u) | (hi & 0xffu);
 }
 
 extern "C" int offsim_compile_digests(const offsim_table *t, const uint64_t *keys, int32_t format, uint32_t *dig32_out, void *stream) {
     int rc = check_table(t);
     if (rc) return rc;
     if (t->N > 0 && (!keys || !dig32_out)) return fail(OFFSIM_EINVAL, "compile_digests: bad argument%s");
-    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "compile_digests: bad format%s");
+    if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B && format != OFFSIM_STREAMS_C) return fail(OFFSIM_EINVAL, "compile_digests: bad format%s");
     if (format == OFFSIM_STREAMS_B && t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format B holds 8-bit states%s");
+    if (format == OFFSIM_STREAMS_C && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format C holds 255 states%s");
     if (t->N == 0) return OFFSIM_OK;
     hipLaunchKernelGGL(k_key_digests, dim3((unsigned)((t->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, t->N, format, dig32_out);
     LAUNCH_CHECK();
@@ -1720,10 +1735,11 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
     // positions inside a state's queue travel in 17-bit fields of the request descriptors and as 16-bit local rows (loc)
-    if (sm->format != OFFSIM_STREAMS_A && sm->format != OFFSIM_STREAMS_B) return fail(OFFSIM_EINVAL, "eval_mc_streams: bad stream format%s");
-    if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > (sm->format == OFFSIM_STREAMS_B ? (1ll << 23) : 65536ll)))
-        return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (format A) / 2^23 (format B)%s");
-    if (sm->format == OFFSIM_STREAMS_B && !sm->loc) return fail(OFFSIM_EINVAL, "eval_mc_streams: format B needs the loc stream%s");
+    if (sm->format != OFFSIM_STREAMS_A && sm->format != OFFSIM_STREAMS_B && sm->format != OFFSIM_STREAMS_C) return fail(OFFSIM_EINVAL, "eval_mc_streams: bad stream format%s");
+    if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > (sm->format == OFFSIM_STREAMS_B ? (1ll << 23) : sm->format == OFFSIM_STREAMS_C ? (1ll << 17) : 65536ll)))
+        return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (format A) / 2^23 (B) / 2^17 (C)%s");
+    if (sm->format != OFFSIM_STREAMS_A && !sm->loc) return fail(OFFSIM_EINVAL, "eval_mc_streams: formats B and C need the loc stream%s");
+    if (sm->format == OFFSIM_STREAMS_C && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: format C holds 255 states%s");
     if (ro->R == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool trace = out->trace_row || out->trace_pop;
@@ -1755,6 +1771,10 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
         if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_B, waves * 64);
         else if (!helper) LAUNCH_ROWS(false, false, OFFSIM_STREAMS_B, waves * 64);
         else LAUNCH_ROWS(false, true, OFFSIM_STREAMS_B, waves * 128);  // a helper wavefront per chain wavefront
+    } else if (sm->format == OFFSIM_STREAMS_C) {
+        if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_C, waves * 64);
+        else if (!helper) LAUNCH_ROWS(false, false, OFFSIM_STREAMS_C, waves * 64);
+        else LAUNCH_ROWS(false, true, OFFSIM_STREAMS_C, waves * 128);
     } else {
         if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_A, waves * 64);
         else if (!helper) LAUNCH_ROWS(false, false, OFFSIM_STREAMS_A, waves * 64);

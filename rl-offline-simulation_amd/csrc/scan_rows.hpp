@@ -137,17 +137,21 @@ __device__ __forceinline__ uint32_t rows_bias(uint32_t dig, uint32_t bias) { ret
 //   A  [T21 | done | z_next 10]                          threshold to 21 bits; the local row is the 16-bit loc entry (segments <= 65536 rows)
 //   B  [T16 | hi 6..2 | done | hi 1..0 | z_next 8]       threshold to 16 bits; hi = bits 16..22 of the local row, the loc entry its low 16
 //                                                        bits (segments of up to 2^23 rows, <= 256 states): still 4 + 2 bytes per position
+//   C  [T14 | hi 8..2 | done | hi 1..0 | z_next 8]       threshold to 14 bits; hi = bits 8..16 of the local row, the loc entry ONE byte
+//                                                        (segments of up to 2^17 rows, <= 255 states): 4 + 1 bytes per position
 // Everything that differs between them is a constant of the launch: where the threshold starts, which low bits travel with a key, the
-// bias and the exact-look band (in threshold units: 16 and 17 of T21, 2 and 3 of T16), how a draw is laid down in the ring.
+// bias and the exact-look band (in threshold units: 16 and 17 of T21, 2 and 3 of T16 / T14), how a draw is laid down in the ring,
+// how many bits of a local row the loc stream holds.
 struct RowsFormat {
-    uint32_t tshift, paymask, zmask, smask, bias, amb, emask;
+    uint32_t tshift, paymask, zmask, smask, bias, amb, emask, locbits;
 };
 __host__ __device__ constexpr RowsFormat rows_format(int fmt) {  // (the format is a template parameter of the kernel: these are immediates)
-    return fmt == OFFSIM_STREAMS_B ? RowsFormat{16u, 0xffffu, 0x4ffu, 0xffu, 2u << 16, 0u - (3u << 16), ROWS_LOG_KMASK | 0xfb00u}
-                                   : RowsFormat{11u, 0x7ffu, 0x7ffu, 0x3ffu, ROWS_BIAS, ROWS_AMB, ROWS_LOG_KMASK};
+    return fmt == OFFSIM_STREAMS_B   ? RowsFormat{16u, 0xffffu, 0x4ffu, 0xffu, 2u << 16, 0u - (3u << 16), ROWS_LOG_KMASK | 0xfb00u, 16u}
+           : fmt == OFFSIM_STREAMS_C ? RowsFormat{18u, 0x3ffffu, 0x4ffu, 0xffu, 2u << 18, 0u - (3u << 18), ROWS_LOG_KMASK | 0x3fb00u, 8u}
+                                     : RowsFormat{11u, 0x7ffu, 0x7ffu, 0x3ffu, ROWS_BIAS, ROWS_AMB, ROWS_LOG_KMASK, 16u};
 }
-// bits 16.. of the local row out of a format-B payload (digest or key): bits 8, 9 and 11..15
-__device__ __forceinline__ uint32_t rows_loc_hi(uint32_t pay) { return ((pay >> 8) & 3u) | (((pay >> 11) & 0x1fu) << 2); }
+// the upper bits of the local row out of a format-B / C PAYLOAD (a digest or key masked with the format's paymask): bits 8, 9 and 11..
+__device__ __forceinline__ uint32_t rows_loc_hi(uint32_t pay) { return ((pay >> 8) & 3u) | (((pay >> 11) & 0x7fu) << 2); }
 
 // Cache policy of the reward pipeline's loads (local row of a served candidate, its reward; one dword out of a sector that is not
 // looked at again): NON-TEMPORAL.  With the default policy these 128 B per accepted step pass through L2 and push out the digest
@@ -252,7 +256,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t win_a = rbase + RO_WIN, cons_a = win_a + n_slots * 32u, land_a = cons_a + n_slots * 4u, claim_a = land_a + n_slots * 4u;
     const uint32_t sync_a = rbase + RO_SYNC;
     constexpr RowsFormat F = rows_format(FMT);
-    constexpr bool fmt_b = FMT == OFFSIM_STREAMS_B;
+    constexpr bool fmt_b = FMT != OFFSIM_STREAMS_A;  // B, C: the digest carries the upper bits of the local row
+    constexpr bool fmt_c = FMT == OFFSIM_STREAMS_C;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
     if (HELPER && !is_helper && li < 8u) LV32(sync_a + li4) = 0u;
@@ -272,7 +277,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     auto seg_at = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t { return LV32(seg_a + s * 4u); };
 
     const uint32_t *dbase = sm.dig + rr * sm.dig_stride;
-    const uint16_t *lbase = sm.loc ? sm.loc + rr * sm.loc_stride : nullptr;
+    constexpr uint32_t LOCB = F.locbits / 8u;  // bytes of a loc-stream entry
+    const unsigned char *lbase = sm.loc ? (const unsigned char *)sm.loc + rr * sm.loc_stride * (int64_t)LOCB : nullptr;
+    auto loc_at = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {
+        return LOCB == 1u ? (uint32_t)lbase[idx] : (uint32_t)((const uint16_t *)lbase)[idx];
+    };
     const uint32_t *init_row = ro.init_perm ? ro.init_perm + rr * ro.init_stride : nullptr;
     uint32_t *cur_glb = ro.cursor + rr * n_slots;
     const uint64_t *rng4 = ro.rng + 4 * rr;
@@ -506,18 +515,18 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint32_t k21 = LV32(rbase + RO_RING + (((c + li) & (ROWS_RING - 1u)) << 2)) >> F.tshift;
             bool ok = valid && k21 <= (dg >> F.tshift);
             if (ok && k21 == (dg >> F.tshift)) {  // tie at the digest's resolution: k53 of draw c+li against the full T
-                const uint32_t lc = lbase ? ((uint32_t)lbase[beg + cz + li] | (fmt_b ? rows_loc_hi(dg) << 16 : 0u)) : cz + li;
+                const uint32_t lc = lbase ? (loc_at(beg + cz + li) | (fmt_b ? rows_loc_hi(dg & F.paymask) << F.locbits : 0u)) : cz + li;
                 ok = !(rows_exact53(rng4, (uint64_t)c + li + 1u) > key_T(keys[beg + lc]));
             }
-            const uint32_t fk = row_min16(ok ? ((li << 16) | (dg & 0xffffu)) : 0xffffffffu);  // first accepted lane and the low half of its digest
+            const uint32_t fk = row_min16(ok ? ((li << 20) | (dg & F.paymask)) : 0xffffffffu);  // first accepted lane and its digest's payload
             if (fk == 0xffffffffu) {  // all of them rejected: consumed (one draw each)
                 c += nv;
                 cz += nv;
                 popped += nv;
                 continue;
             }
-            const uint32_t acc = fk & 0xffffu;
-            const uint32_t k1 = (fk >> 16) + 1u;
+            const uint32_t acc = fk & 0xfffffu;
+            const uint32_t k1 = (fk >> 20) + 1u;
             c += k1;
             const uint32_t cz1 = cz + k1;
             log_step(it, rows_log_word(z, acc & 0x400u, popped + k1));
@@ -647,7 +656,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             // (Every load of the pipeline is issued by every lane -- one without work reads the rollout's own stream state -- so
             // that a round issues a FIXED number of vector-memory instructions: the helper's waits count them, ROWS_VM_*.)
             const bool act = li < n1;
-            const uint32_t lc = lbase ? (((half1 ? in_loc >> 16 : in_loc) & 0xffffu) | (lh1 << 16)) : in_loc;
+            const uint32_t lc = lbase ? (((in_loc >> half1) & ((1u << F.locbits) - 1u)) | (lh1 << F.locbits)) : in_loc;
             const uint32_t g = rowb1 + lc;
             if (r64) {
                 const uint32_t *src = act ? (const uint32_t *)((const double *)t.r + g) : (const uint32_t *)rng4;
@@ -674,8 +683,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             uint32_t hf = 0;
             const uint32_t rb = mine ? seg_at(s_i) : 0u;
             if (lbase) {
-                const uint64_t a16 = mine ? (uint64_t)(uintptr_t)(lbase + rb + pos_i) : (uint64_t)(uintptr_t)rng4;
-                hf = (uint32_t)(a16 >> 1) & 1u;
+                const uint64_t a16 = mine ? (uint64_t)(uintptr_t)(lbase + (uint64_t)(rb + pos_i) * LOCB) : (uint64_t)(uintptr_t)rng4;
+                hf = ((uint32_t)a16 & 3u) * 8u;  // where the entry starts inside its dword, in bits
                 lds_dma_dword((const void *)(uintptr_t)(a16 & ~3ull), dma_a + DS_LOC * 256u);
             } else if (mine) {
                 LV32(dma_a + DS_LOC * 256u + lane * 4u) = pos_i;  // table order: the local row is the queue position
@@ -1312,7 +1321,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         // first; label 50: the handler.  Temporaries: hv = %[nrd] (entries the window held), p = %[e] (queue position behind the
         // window), dg = %[w2] (sixteen candidates, lane = position), v[120:121] = the state's segment, v122 = compare, v123 = land
         // address / scratch, v[124:125] = address, v126, v127, v117..v119 scratch; s[30:31] = the rows without a clear accept,
-        // s[32:33] = lanes.  Nothing of the iteration is committed before the last test has passed; what it leaves for the entry
+        // s[42:43] = lanes.  Nothing of the iteration is committed before the last test has passed; what it leaves for the entry
         // code: the state and the reads of the next look, and in `key` the log word of this step (the first copy after an entry
         // writes "the step before it" from key).
 #ifdef ROWS_DRY_BISECT1  /* (debug build: every dry event leaves for the C++ path after the handler's tests) */
@@ -1474,8 +1483,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             /* may every row that needs one take an initial state?  (a dry row's step may end an episode: asked of all of them) */ \
             "v_and_b32 v117, 0x400, %[key]\n\t"                                                                           \
             "v_cmp_ne_u32_e32 vcc, 0, v117\n\t"                                                                           \
-            "v_cmp_eq_u32_e64 s[32:33], 0, %[left]\n\t"                                                                   \
-            "s_and_b64 s[32:33], s[32:33], vcc\n\t"                      /* (the all-ones key carries the done bit: covers the dry rows) */ \
+            "v_cmp_eq_u32_e64 s[42:43], 0, %[left]\n\t"                                                                   \
+            "s_and_b64 s[42:43], s[42:43], vcc\n\t"                      /* (the all-ones key carries the done bit: covers the dry rows) */ \
             "s_cbranch_scc1 2f\n\t"                                                                                       \
             /* entries the window held: lanes 0..7 (8..15 repeat them) */                                                \
             "v_cmp_ne_u32_e32 vcc, 0, %[w]\n\t"                                                                           \
@@ -1503,9 +1512,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_add_u32 v127, 0xffffff01, %[c4]\n\t"                                                                       \
             "v_lshl_add_u32 v127, %[nrd], 2, v127\n\t"                                                                    \
             "v_sub_u32 v127, v127, v110\n\t"                             /* 4 x draws consumed */                        \
-            "s_sub_u32 s32, 17, %[it]\n\t"                               /* this event's sixteen draws, and eight for every look left in the tick (the loop */ \
-            "s_lshl_b32 s32, s32, 5\n\t"                                 /* itself never checks: a tick's worth is in the ring when it starts): 4 x (16 + 8 (15 - it)) */ \
-            "v_add_u32 v126, s32, v127\n\t"                                                                               \
+            "s_sub_u32 s42, 17, %[it]\n\t"                               /* this event's sixteen draws, and eight for every look left in the tick (the loop */ \
+            "s_lshl_b32 s42, s42, 5\n\t"                                 /* itself never checks: a tick's worth is in the ring when it starts): 4 x (16 + 8 (15 - it)) */ \
+            "v_add_u32 v126, s42, v127\n\t"                                                                               \
             "v_cmp_gt_u32_e32 vcc, v126, %[gen4]\n\t"                    /* ... are not known to be in the ring */     \
             "s_and_b64 vcc, vcc, s[30:31]\n\t"                                                                            \
             "s_cbranch_vccnz 2f\n\t"                                                                                      \
@@ -1519,10 +1528,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_cndmask_b32_e32 v122, v125, v122, vcc\n\t"                                                                 \
             "v_sub_co_u32 v126, vcc, v122, v117\n\t"                     /* borrow: not a clear accept */                \
             "v_and_or_b32 %[zn], %[w2], v112, v119\n\t"                                                                   \
-            "v_cmp_le_u32_e64 s[32:33], v114, v126\n\t"                  /* a lane near a tie: the C++ path */           \
+            "v_cmp_le_u32_e64 s[42:43], v114, v126\n\t"                  /* a lane near a tie: the C++ path */           \
             "v_cndmask_b32_e64 %[zn], %[zn], -1, vcc\n\t"                                                                 \
             "s_mov_b64 exec, s[30:31]\n\t"                             /* (all sixteen lanes of the dry rows again) */  \
-            "s_cmp_lg_u64 s[32:33], 0\n\t"                                                                                \
+            "s_cmp_lg_u64 s[42:43], 0\n\t"                                                                                \
             "s_cbranch_scc1 52f\n\t"                                                                                      \
             "v_min_u32_dpp %[zn], %[zn], %[zn] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                        \
             "s_nop 1\n\t"                                                                                                 \
@@ -1558,9 +1567,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_sub_u32 v124, %[ra], v110\n\t"                                                                             \
             "v_cmp_gt_u32_e32 vcc, 32, v126\n\t"                                                                          \
             "v_add_u32 v124, v124, v126\n\t"                                                                              \
-            "v_cmp_lt_u32_e64 s[32:33], v118, v121\n\t"                  /* (only the sector's candidates) */            \
+            "v_cmp_lt_u32_e64 s[42:43], v118, v121\n\t"                  /* (only the sector's candidates) */            \
             "s_and_b64 exec, exec, vcc\n\t"                                                                               \
-            "s_and_b64 exec, exec, s[32:33]\n\t"                                                                          \
+            "s_and_b64 exec, exec, s[42:43]\n\t"                                                                          \
             "ds_write_b32 v124, v122\n\t"                                                                                 \
             "s_mov_b64 exec, %[live]\n\t"                                                                                 \
             /* ---- all rows: the key that counts, the log word, the next state ---- */                                  \
@@ -1695,7 +1704,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
               [rb] "=&v"(rb), [w2] "=&v"(w2), [amb] "=&s"(amb), [ev] "=&s"(ev), [it] "+s"(it)                                                           \
             : [ringa] "v"(ring_a), [claimb] "v"(claim_a), [dmaa] "s"(dma_a), [li4] "v"(li4), [landb] "v"(land_a), [gen4] "v"(gen4), [dbase] "v"(dbase), [sega] "s"(seg_a),  \
               [live] "s"(live)                                                                                                                           \
-            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s30", "s31", "s32", "s33", "v110", "v111", "v112",        \
+            : "vcc", "scc", "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s30", "s31", "s42", "s43", "v110", "v111", "v112",        \
               "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v96", "v97",       \
               "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "s36", "s37", "s38", "s39", "s40", "s41")
         static_assert(RO_WIN - RO_RING == 0x5c0u && DS_RQD * 256u == 2048u && DS_RQS * 256u == 2304u && DS_RQ_SET * 256u == 2560u && DS_RQB * 256u == 1024u, "immediates of the loop");
@@ -1704,7 +1713,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                       rows_format(OFFSIM_STREAMS_A).bias == 0x8000u && rows_format(OFFSIM_STREAMS_A).smask == 0x3ffu, "the literals of the format-A loop");
         static_assert(rows_format(OFFSIM_STREAMS_B).paymask == 0xffffu && rows_format(OFFSIM_STREAMS_B).zmask == 0x4ffu &&
                       rows_format(OFFSIM_STREAMS_B).amb == 0xfffd0000u && (rows_format(OFFSIM_STREAMS_B).emask | 0x400u) == 0x3c00ff00u, "the literals of the format-B loop");
-        if constexpr (fmt_b) {
+        static_assert(rows_format(OFFSIM_STREAMS_C).paymask == 0x3ffffu && rows_format(OFFSIM_STREAMS_C).zmask == 0x4ffu &&
+                      rows_format(OFFSIM_STREAMS_C).amb == 0xfff40000u && (rows_format(OFFSIM_STREAMS_C).emask | 0x400u) == 0x3c03ff00u, "the literals of the format-C loop");
+        if constexpr (fmt_c) {
+            ROWS_FAST_ASM("0x3ffff", "0x4ff", "0xfff40000", "0x3c03ff00", "6", "");
+        } else if constexpr (fmt_b) {
             ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
         } else {
 #if defined(ROWS_NO_DRY_ASM) || (defined(ROWS_DRY_STAGE) && ROWS_LAND_LAG != 2)  // A/B builds: every row without a clear accept takes the C++ path, as in round 3

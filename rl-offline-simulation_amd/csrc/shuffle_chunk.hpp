@@ -66,8 +66,16 @@ __device__ __forceinline__ uint32_t shc_take(lds_vu32 *p) {
 __device__ __forceinline__ uint32_t shc_xchg(lds_vu32 *p, uint32_t v) {
     return __hip_atomic_exchange((__attribute__((address_space(3))) uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// bits 16.. of a local row where the digest word of stream format B carries them (bits 8, 9 and 11..15)
-__host__ __device__ inline uint32_t shc_hi_bits(uint32_t loc) { return (((loc >> 16) & 3u) << 8) | ((loc >> 18) << 11); }
+// the upper bits h of a local row (bits 16.. in stream format B, bits 8.. in format C) where the digest word carries them: bits 8, 9 and 11..
+__host__ __device__ inline uint32_t shc_hi_bits(uint32_t h) { return ((h & 3u) << 8) | ((h >> 2) << 11); }
+// entry k of a loc stream of `loc_bits`-bit entries (16: formats A, B; 8: format C)
+__device__ __forceinline__ void shc_loc_store(unsigned char *lc, uint32_t k, uint32_t v, uint32_t loc_bits) {
+    if (loc_bits == 8u) lc[k] = (unsigned char)v;
+    else ((uint16_t *)lc)[k] = (uint16_t)v;
+}
+__device__ __forceinline__ uint32_t shc_loc_load(const unsigned char *lc, uint32_t k, uint32_t loc_bits) {
+    return loc_bits == 8u ? (uint32_t)lc[k] : (uint32_t)((const uint16_t *)lc)[k];
+}
 // message pool entries a workgroup needs for segments of up to n rows (host side: sizes the workspace)
 inline uint64_t shc_pool_entries(uint32_t n, uint32_t cb) {
     uint64_t tot = 0;
@@ -86,8 +94,8 @@ __global__ void __launch_bounds__(256)
     k_shuffle_chunked(const uint32_t *__restrict__ seg_off, int64_t N, const uint64_t *__restrict__ seeds, int32_t n_perm,
                       const uint32_t *__restrict__ work_seg, const uint32_t *__restrict__ n_work_seg, uint32_t *__restrict__ counter, uint64_t *__restrict__ ws,
                       int64_t ws_block_words, uint32_t msg_cap, uint32_t kcap, const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out,
-                      uint16_t *__restrict__ loc_out, int32_t n_slots, int64_t N0, uint32_t *__restrict__ init_perm, uint32_t *__restrict__ perm_out,
-                      int64_t lc_words) {
+                      void *__restrict__ loc_out, int32_t n_slots, int64_t N0, uint32_t *__restrict__ init_perm, uint32_t *__restrict__ perm_out,
+                      int64_t lc_words, uint32_t loc_bits) {
     constexpr uint32_t JB = __builtin_ctz(CB);  // bits of a position inside its chunk
     static_assert((CB & (CB - 1u)) == 0u && JB <= 15u, "chunk size: a power of two, at most 32768 (a position inside its chunk travels in 15 bits)");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(256)
     uint64_t *rpool = m64 + msg_cap + (PLAIN ? 0u : (msg_cap + 1u) / 2u);  // (PLAIN: a message is one word: row 23 bits | j << 23 | i << (23 + JB))
     // (chains whose records are plain row indices -- the init queue, and every chain when the orders go out as permutations, perm_out != NULL --
     // have no use for the records' low halves: those are written to this scratch area)
-    uint16_t *lc_plain = (uint16_t *)(m64 + ws_block_words - lc_words);
+    unsigned char *lc_plain = (unsigned char *)(m64 + ws_block_words - lc_words);
     const uint32_t n_work = n_work_seg[0] * (uint32_t)n_perm;
 
     for (;;) {
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t beg = initq ? 0u : seg_off[s], n = initq ? (uint32_t)N0 : seg_off[s + 1] - beg;
         const uint32_t K = (n + CB - 1u) / CB;  // (<= kcap: the launch sized the list arrays for the table's longest state)
         uint32_t *dg = initq ? init_perm + (int64_t)r * N0 : (perm_out ? perm_out : dig_out) + (int64_t)r * N + beg;
-        uint16_t *lc = plain ? lc_plain : loc_out + (int64_t)r * N + beg;
+        unsigned char *lc = plain ? lc_plain : (unsigned char *)loc_out + ((int64_t)r * N + beg) * (int64_t)(loc_bits >> 3);
         const uint32_t base_val = initq ? 0u : beg;  // (a plain record = the grouped row, or the index into the init rows)
         const uint32_t *dsrc = plain ? seg_off : dig32 + beg;  // (plain records: never read)
         __syncthreads();  // (everyone has read SC_WORK)
@@ -296,8 +304,8 @@ __global__ void __launch_bounds__(256)
                         for (int u = 0; u < 16; u++) {
                             const uint32_t k = k0 + 64u * (uint32_t)u, loc = lo + k;
                             if (k < m) {
-                                xd[k] = PLAIN ? loc : plain ? base_val + loc : (dv[u] | shc_hi_bits(loc));  // (PLAIN: the base goes on at the stores)
-                                if (!PLAIN) xl[k] = loc & 0xffffu;
+                                xd[k] = PLAIN ? loc : plain ? base_val + loc : (dv[u] | shc_hi_bits(loc >> loc_bits));  // (PLAIN: the base goes on at the stores)
+                                if (!PLAIN) xl[k] = loc & ((1u << loc_bits) - 1u);
                             }
                         }
                     }
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(256)
                             const uint32_t k = k0 + 64u * (uint32_t)u;
                             if (k < m) {
                                 dg[lo + k] = PLAIN ? base_val + vd[u] : vd[u];
-                                if (!PLAIN) lc[lo + k] = (uint16_t)vl[u];
+                                if (!PLAIN) shc_loc_store(lc, lo + k, vl[u], loc_bits);
                             }
                         }
                     }
@@ -470,7 +478,7 @@ __global__ void __launch_bounds__(256)
             }
         } else if (threadIdx.x == 0) {  // a state with a single row
             dg[0] = plain ? base_val : dsrc[0];  // (a single row)
-            if (!PLAIN) lc[0] = 0;
+            if (!PLAIN) shc_loc_store(lc, 0u, 0u, loc_bits);
         }
         __syncthreads();
 #ifdef SHC_PROF
@@ -485,19 +493,19 @@ __global__ void __launch_bounds__(256)
             if (cnt == 0u) continue;
             for (uint32_t k0 = threadIdx.x; k0 < m; k0 += 2048u) {
                 uint32_t vd[8];
-                uint16_t vl[8];
+                uint32_t vl[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
                     vd[u] = k < m ? dg[lo + k] : 0u;
-                    vl[u] = (k < m && !PLAIN) ? lc[lo + k] : (uint16_t)0;
+                    vl[u] = (k < m && !PLAIN) ? shc_loc_load(lc, lo + k, loc_bits) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t k = k0 + 256u * (uint32_t)u;
                     if (k < m) {
                         xd[k] = vd[u];
-                        if (!PLAIN) xl[k] = (uint32_t)vl[u];
+                        if (!PLAIN) xl[k] = vl[u];
                     }
                 }
             }
@@ -522,7 +530,7 @@ __global__ void __launch_bounds__(256)
             __syncthreads();
             for (uint32_t k = threadIdx.x; k < m; k += 256u) {
                 dg[lo + k] = xd[k];
-                if (!PLAIN) lc[lo + k] = (uint16_t)xl[k];
+                if (!PLAIN) shc_loc_store(lc, lo + k, xl[k], loc_bits);
             }
             __syncthreads();
         }

@@ -52,6 +52,20 @@ def _gamma_pow(gamma, n, device, cap=None):
     return _GP_CACHE[key]
 
 
+def stream_format(table):
+    """Layout of the candidate streams of `table` (include/offsim.h): A while every state has at most 65536 rows (21-bit thresholds, 16-bit
+    local rows); C for states of up to 2^17 rows (14-bit thresholds, the local row's bits 8.. inside the digest, ONE byte beside it: 5
+    bytes per queue position instead of 6 -- what lets a 12.5 M-row shard keep 4096 rollouts resident at once; written by the chunked
+    shuffle only, so not with OFFSIM_SHUFFLE_CHUNKED=0); B beyond (16-bit thresholds, bits 16.. inside the digest).
+    OFFSIM_STREAMS_FORMAT=B keeps B where C would apply (A/B runs)."""
+    if table.max_seg <= 65536:
+        return L.STREAMS_A
+    if (table.max_seg <= (1 << 17) and table.n_slots <= 255 and os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") != "0"
+            and os.environ.get("OFFSIM_STREAMS_FORMAT", "") != "B"):
+        return L.STREAMS_C
+    return L.STREAMS_B
+
+
 def _prob_mode(table, p_dtype):
     f32 = (p_dtype in (np.float32, torch.float32, np.dtype(np.float32))) and table.p_log.dtype == torch.float32
     return L.PROB_F32 if f32 else L.PROB_F64
@@ -111,7 +125,7 @@ class BatchedPSRS:
                 self._perm_buf = None  # (the two forms of the orders are not kept side by side: 4 + 6 bytes per entry and rollout)
                 if self._dig_buf is None or self._dig_buf.shape[0] != self.R:
                     self._dig_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int32, device=dev)
-                    self._loc_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.int16, device=dev)
+                    self._loc_buf = torch.empty((self.R, max(t.N, 1)), dtype=torch.uint8 if self._loc_bits() == 8 else torch.int16, device=dev)
                 keys, dig32 = self._policy_keys(policy)
                 ws = self._shuffle_workspace()
                 L.check(L.load().offsim_shuffle_queues_keys_ws(C.byref(t.c), L.ptr(sd), self.R, L.ptr(dig32), self._stream_format(), L.ptr(self._dig_buf),
@@ -218,9 +232,25 @@ class BatchedPSRS:
         return self._acc_cache[1]
 
     def _stream_format(self):
-        """Layout of the digest stream (include/offsim.h): A while every state has at most 65536 rows (21-bit thresholds, 16-bit local
-        rows), B beyond (16-bit thresholds, the local row's upper bits inside the digest)."""
-        return L.STREAMS_A if self.table.max_seg <= 65536 else L.STREAMS_B
+        """Layout of the candidate streams (module function stream_format; settled at first use: buffers written in one layout are
+        read in that layout whatever the environment says later)."""
+        f = self.__dict__.get("_fmt")
+        if f is None:
+            f = self._fmt = stream_format(self.table)
+        return f
+
+    def _loc_bits(self):
+        """Bits of the local row the loc stream holds (the others travel inside the digest: formats B, C)."""
+        return 8 if self._stream_format() == L.STREAMS_C else 16
+
+    def _local_rows(self, loc, dig):
+        """Local rows (int64) out of slices of the two streams."""
+        lb = self._loc_bits()
+        local = loc.to(torch.int64) & ((1 << lb) - 1)
+        if self._stream_format() != L.STREAMS_A:
+            dg = dig.to(torch.int64)
+            local |= (((dg >> 8) & 3) | (((dg >> 11) & (0x7F if lb == 8 else 0x1F)) << 2)) << lb
+        return local
 
     @staticmethod
     def _policy_key(policy):
@@ -270,33 +300,31 @@ class BatchedPSRS:
         t = self.table
         _, dig32 = self._policy_keys(policy, key=key)
         base = self._seg_base()
-        fmt_b = self._stream_format() == L.STREAMS_B
         step = max(1, (128 << 20) // max(t.N * 8, 1))
         for b in range(0, self.R, step):
-            local = self._loc_buf[b:b + step, :t.N].to(torch.int64) & 0xFFFF
-            if fmt_b:
-                dg = self._dig_buf[b:b + step, :t.N].to(torch.int64)
-                local |= (((dg >> 8) & 3) | (((dg >> 11) & 0x1F) << 2)) << 16
+            local = self._local_rows(self._loc_buf[b:b + step, :t.N], self._dig_buf[b:b + step, :t.N])
             self._dig_buf[b:b + step, :t.N] = self._pack_streams(dig32, local + base[None, :])[0]
         self._streams = dict(dig=self._dig_buf, dig_stride=t.N, loc=self._loc_buf, loc_stride=t.N, key=key, format=self._stream_format())
 
     def _pack_streams(self, dig32, p):
         """(dig, loc) streams of queue orders given as grouped rows p [..., N] (int64): the digest of the row at every position -- in
-        format B with bits 16.. of its local row in the digest's bits 8, 9, 11..15 -- and the local row's low 16 bits."""
+        formats B / C with bits 16.. / 8.. of its local row in the digest's bits 8, 9, 11.. -- and the local row's low 16 / 8 bits."""
         local = p - (self._seg_base() if p.dim() == 1 else self._seg_base()[None, :])
         dg = dig32[p].to(torch.int64) & 0xFFFFFFFF
-        if self._stream_format() == L.STREAMS_B:
-            h = local >> 16
+        lb = self._loc_bits()
+        if self._stream_format() != L.STREAMS_A:
+            h = local >> lb
             dg = dg | ((h & 3) << 8) | ((h >> 2) << 11)
         dg = torch.where(dg >= 2 ** 31, dg - 2 ** 32, dg).to(torch.int32)
-        return dg.contiguous(), (local & 0xFFFF).to(torch.int16).contiguous()
+        lo = local & ((1 << lb) - 1)
+        return dg.contiguous(), (lo.to(torch.uint8) if lb == 8 else torch.where(lo >= 2 ** 15, lo - 2 ** 16, lo).to(torch.int16)).contiguous()
 
     def _table_order_streams(self, dig32, key):
         """Streams of queues in table order (no shuffle): format A needs no loc stream (the local row is the queue position)."""
         if self._stream_format() == L.STREAMS_A:
             return dict(dig=dig32, dig_stride=0, loc=None, loc_stride=0, key=key, format=L.STREAMS_A)
         dg, lc = self._pack_streams(dig32, torch.arange(self.table.N, device=self.table.device, dtype=torch.int64))
-        return dict(dig=dg, dig_stride=0, loc=lc, loc_stride=0, key=key, format=L.STREAMS_B)
+        return dict(dig=dg, dig_stride=0, loc=lc, loc_stride=0, key=key, format=self._stream_format())
 
     def _seg_base(self):
         """seg_off of the state every grouped position belongs to ([N] int64)."""
@@ -309,11 +337,7 @@ class BatchedPSRS:
         """Queue orders as permutations of grouped rows [R or 1, N] (built from the streams when the reset wrote those)."""
         if self.state.perm is not None or self._perm_lazy != "streams":
             return self.state.perm
-        local = self._loc_buf.to(torch.int64) & 0xFFFF
-        if self._stream_format() == L.STREAMS_B:
-            dg = self._dig_buf.to(torch.int64)
-            local = local | ((((dg >> 8) & 3) | (((dg >> 11) & 0x1F) << 2)) << 16)
-        return (local + self._seg_base()[None, :]).to(torch.int32)
+        return (self._local_rows(self._loc_buf, self._dig_buf) + self._seg_base()[None, :]).to(torch.int32)
 
     def set_rejection_seeds(self, seeds, provider="pcg64"):
         """Replace only the rejection streams (env.rejection_sampling_rng = ..., psrs.py:20 is a plain attribute).
@@ -632,7 +656,8 @@ class BatchedPSRS:
 def rollout_resident_bytes(table, keyed=True):
     """HBM one rollout keeps resident between reset_sampler and the scan: its queue orders (candidate streams: 4 + 2 bytes per queue
     position; as permutations: 4), its init order, cursors and random-stream state."""
-    return int(table.N) * (6 if keyed else 4) + int(table.N0) * 4 + int(table.n_slots) * 4 + 64
+    per_pos = 4 if not keyed else 5 if stream_format(table) == L.STREAMS_C else 6
+    return int(table.N) * per_pos + int(table.N0) * 4 + int(table.n_slots) * 4 + 64
 
 
 def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, tile=None,

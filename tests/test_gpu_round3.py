@@ -158,10 +158,8 @@ def test_shuffle_protocol_slip_ends_with_an_error_not_a_hang(gpu):
     offsim_async_faults() / check_async_faults() report it.  Run in a child process (the library is chosen per process)."""
     import os, subprocess, sys, time
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
-                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    from _variants import fault_lib
+    lib = fault_lib()
     code = """
 import sys, time
 sys.path.insert(0, %r)
@@ -303,6 +301,7 @@ for n, nS, R in shapes:
     pi = table.policy_slots(synth.dirichlet_policy(nS, 2))
     seeds = [int(x) for x in np.random.default_rng(n).integers(0, 1 << 62, R)]
     out = {}
+    os.environ["OFFSIM_STREAMS_FORMAT"] = "B"  # (the same layout from both kernels; the 5-byte layout only the chunked kernel writes: below)
     for mode in ("1", "0"):
         os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
         env = BatchedPSRS(table, R)
@@ -313,6 +312,14 @@ for n, nS, R in shapes:
         out[mode] = env
     assert torch.equal(out["1"]._dig_buf, out["0"]._dig_buf) and torch.equal(out["1"]._loc_buf, out["0"]._loc_buf), (n, nS)
     assert torch.equal(out["1"]._init_perm_buf, out["0"]._init_perm_buf), (n, nS)
+    del os.environ["OFFSIM_STREAMS_FORMAT"]
+    os.environ["OFFSIM_SHUFFLE_CHUNKED"] = "1"
+    envc = BatchedPSRS(table, R)  # stream format C where it applies (states of 65537 .. 131072 rows): every chain on the chunked kernel
+    envc.reset_sampler(seeds, policy=pi)
+    torch.cuda.synchronize()
+    assert L.load().offsim_async_faults() == 0
+    assert (envc._streams["format"] == L.STREAMS_C) == (65536 < table.max_seg <= 131072 and nS <= 255), (n, nS)
+    assert torch.equal(envc.perm, out["0"].perm) and torch.equal(envc._init_perm_buf, out["0"]._init_perm_buf), (n, nS)
     plain = {}
     for mode in ("1", "0"):  # the same chains as permutations (offsim_shuffle_queues_ws)
         os.environ["OFFSIM_SHUFFLE_CHUNKED"] = mode
@@ -351,10 +358,8 @@ def test_chunked_shuffle_list_overflow_raises_the_fault_and_a_small_workspace_fa
     not hold one workgroup's pools gives the in-place shuffle -- same orders."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(os.path.dirname(here), "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
-                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    from _variants import fault_lib
+    lib = fault_lib()
     code = """
 import sys, time
 sys.path.insert(0, %r)

@@ -22,8 +22,8 @@ def gpu():
     return torch.device("cuda", 0)
 
 
-@pytest.mark.parametrize("nS,N", [(20, 40_000), (2, 180_000)])  # stream format A; format B (states of more than 65536 rows)
-def test_second_policy_on_the_same_sampler_state_rekeys_the_streams(nS, N, gpu):
+@pytest.mark.parametrize("nS,N,fmt", [(20, 40_000, "A"), (2, 180_000, "B"), (2, 180_000, "C")])  # states of more than 65536 rows: B, or the 5-byte C
+def test_second_policy_on_the_same_sampler_state_rekeys_the_streams(nS, N, fmt, gpu, monkeypatch):
     """reset_sampler(policy=A) writes the queue orders as A's candidate streams; evaluating policy B afterwards on the same sampler
     state is what the reference allows (evalMC_psrs takes any pi, the queues just go on: psrs.py:241-271).  The streams' digests
     are replaced in place (BatchedPSRS._rekey_streams) and the row-packed kernel goes on -- against the oracle doing the same."""
@@ -31,6 +31,8 @@ def test_second_policy_on_the_same_sampler_state_rekeys_the_streams(nS, N, gpu):
     from rl_offline_simulation_amd import synth, _lib as L
     from rl_offline_simulation_amd.table import TransitionTable
     from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    if fmt == "B":
+        monkeypatch.setenv("OFFSIM_STREAMS_FORMAT", "B")
     e = synth.synth_iid(N, nS, 3, seed=nS + 5)
     t0 = e["steps"] == 0
     table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
@@ -39,6 +41,7 @@ def test_second_policy_on_the_same_sampler_state_rekeys_the_streams(nS, N, gpu):
     env = BatchedPSRS(table, len(seeds))
     env.reset_sampler(seeds, policy=table.policy_slots(pa))
     assert env._streams is not None and env.state.perm is None
+    assert env._streams["format"] == {"A": L.STREAMS_A, "B": L.STREAMS_B, "C": L.STREAMS_C}[fmt]
     o1 = env.eval_mc(table.policy_slots(pa), 0.97, n_episodes=25, ep_cap=table.N0 + 1)
     o1 = {k: v.clone() for k, v in o1.items() if isinstance(v, torch.Tensor)}
     o2 = env.eval_mc(table.policy_slots(pb), 0.97, ep_cap=table.N0 + 1)  # (automatic mode: used to raise "laid out for another policy")
@@ -81,10 +84,8 @@ def test_drop_in_drivers_raise_when_the_sampler_reset_gave_up_a_wait(gpu):
     word.  The host-facing drivers look at it where they synchronise anyway: with the fault-injection build (role A of the shuffle
     never starts, variants/lib_fault.so) PSRS.from_arrays -- reset_sampler() then reset(), psrs.py:13-14 -- raises OffsimError instead
     of serving a void order, and so does VectorPSRS(strict=True).reset_sampler; the word is read and cleared by ONE atomic exchange."""
-    lib = os.path.join(ROOT, "rl-offline-simulation_amd", "csrc", "variants", "lib_fault.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["bash", os.path.join(os.path.dirname(lib), "..", "build.sh"), "-DSHUF_FAULT_INJECT", "-DSHC_TEST_SMALL_LISTS"],
-                              env=dict(os.environ, OUT="variants/lib_fault.so"))
+    from _variants import fault_lib
+    lib = fault_lib()
     code = r'''
 import sys
 sys.path.insert(0, %r)
@@ -174,3 +175,74 @@ def test_step_server_serves_the_same_steps_as_one_launch_per_call(gpu):
         x, sx = run(True, **kw)
         y, sy = run(False, **kw)
         assert len(x) > 100 and x == y and sx == sy, kw
+
+
+def test_five_byte_streams_hold_the_same_orders_and_give_the_same_rollouts(gpu, monkeypatch):
+    """Stream format C (include/offsim.h: 14-bit thresholds, bits 8..16 of the local row inside the digest, ONE byte beside it; every
+    chain on the chunked shuffle) against the permutation form of the same reset, against format B on the same table and against the
+    oracle: a table whose states hold 1, 2, 63 .. 65, 4095 .. 4097, 70000 and exactly 2^17 rows (the most the format takes; chains of
+    one chunk and of a single row run through the chunked kernel here), 255 states; beyond either limit format B serves."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth, _lib as L
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    from rl_offline_simulation_amd.evaluators.psrs import stream_format, rollout_resident_bytes
+    lengths = [1, 2, 63, 64, 65, 4095, 4096, 4097, 70000, 1 << 17]
+    N, nS, nA = sum(lengths), 255, 3
+    e = synth.synth_iid(N, nS, nA, seed=77, p_done=0.05, p_init=0.01)
+    z = np.repeat(np.array([0, 3, 9, 17, 50, 100, 101, 200, 253, 254]), lengths)
+    g = np.random.default_rng(3)
+    g.shuffle(z)
+    e["z"] = z.astype(e["z"].dtype)
+    # next states: mostly the two big states (long rollouts), sometimes the small ones
+    zn = g.choice(np.array([253, 254, 200, 101, 100, 50, 17, 9, 3, 0]), N, p=[0.46, 0.46, 0.04, 0.02, 0.0195, 0.0001, 0.0001, 0.0001, 0.0001, 0.0001])
+    e["z_next"] = zn.astype(e["z_next"].dtype)
+    t0 = e["steps"] == 0
+    args = (e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    table = TransitionTable(*args, device=gpu)
+    assert table.max_seg == 1 << 17 and stream_format(table) == L.STREAMS_C and rollout_resident_bytes(table) < 5 * N + 4 * table.N0 + 2048
+    pi = synth.dirichlet_policy(nS, nA, seed=4)
+    seeds = [11, 12, 13, 14, 15, 16]
+    plain = BatchedPSRS(table, len(seeds))
+    plain.reset_sampler(seeds)
+    envc = BatchedPSRS(table, len(seeds))
+    envc.reset_sampler(seeds, policy=table.policy_slots(pi))
+    torch.cuda.synchronize()
+    L.check_async_faults()
+    assert envc._streams["format"] == L.STREAMS_C and envc._loc_buf.dtype == torch.uint8
+    assert torch.equal(envc.perm.to(torch.int64) & 0xFFFFFFFF, plain.state.perm.to(torch.int64) & 0xFFFFFFFF)
+    assert torch.equal(envc.state.init_perm, plain.state.init_perm)
+    oc = envc.eval_mc(table.policy_slots(pi), 0.98, ep_cap=table.N0 + 1)
+    assert envc.scan_variant() == "k_eval_mc_rows"
+    monkeypatch.setenv("OFFSIM_STREAMS_FORMAT", "B")
+    envb = BatchedPSRS(table, len(seeds))
+    envb.reset_sampler(seeds, policy=table.policy_slots(pi))
+    assert envb._streams["format"] == L.STREAMS_B and envb._loc_buf.dtype == torch.int16
+    ob = envb.eval_mc(table.policy_slots(pi), 0.98, ep_cap=table.N0 + 1)
+    torch.cuda.synchronize()
+    L.check_async_faults()
+    for k in ("steps", "cand", "n_ep", "sum_g", "status", "n_len"):
+        assert torch.equal(oc[k], ob[k]), k
+    assert torch.equal(oc["ep_g"], ob["ep_g"]) and torch.equal(oc["ep_len"], ob["ep_len"])
+    monkeypatch.delenv("OFFSIM_STREAMS_FORMAT")
+    ora = O.OraclePSRS(*args)
+    for i, sd in enumerate(seeds[:3]):
+        ora.reset_sampler(sd)
+        ref = ora.evalmc(10 ** 9, pi, 0.98)
+        ne = int(oc["n_ep"][i])
+        assert int(oc["steps"][i]) == ref["steps"] and int(oc["cand"][i]) == ref["candidates"] and ne == len(ref["Gs"]), (i, sd)
+        assert np.array_equal(oc["ep_g"][i, :ne].cpu().numpy(), ref["Gs"])
+    # derived streams (reset without a policy, streams gathered from the permutations) take the same format
+    envd = BatchedPSRS(table, 2)
+    envd.reset_sampler(seeds[:2])
+    od = envd.eval_mc(table.policy_slots(pi), 0.98, ep_cap=table.N0 + 1)
+    assert envd.scan_variant() == "k_eval_mc_rows" and envd._streams["format"] == L.STREAMS_C
+    for k in ("steps", "cand", "n_ep", "sum_g"):
+        assert torch.equal(od[k], oc[k][:2]), k
+    # one row more per state, or one state more: format B
+    for lens, n_states in (([1, (1 << 17) + 1], 255), ([70000, 5], 256)):
+        n = sum(lens)
+        e2 = synth.synth_iid(n, n_states, 2, seed=5)
+        e2["z"] = np.repeat(np.array([0, n_states - 1]), lens).astype(e2["z"].dtype)
+        t2 = TransitionTable(e2["z"], e2["actions"], e2["rewards"], e2["z_next"], e2["terminals"], e2["action_distributions"], e2["steps"] == 0, device=gpu)
+        assert stream_format(t2) == L.STREAMS_B, (lens, n_states)
