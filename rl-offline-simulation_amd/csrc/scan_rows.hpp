@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     constexpr bool fmt_c = FMT == OFFSIM_STREAMS_C;
     uint32_t dead = r < (int64_t)ro.R ? 0u : 1u;  // 1: the row has stopped (or never ran)
     const int64_t rr = dead ? 0 : r;  // (rows past R read rollout 0's inputs and write nothing)
-    if (HELPER && !is_helper && li < 8u) LV32(sync_a + li4) = 0u;
+    if (!is_helper && li < 8u) LV32(sync_a + li4) = 0u;  // (without helpers SY_TICK stays 0: the dry-row handler takes the log buffer's parity from it)
     if (!is_helper) {  // no request has been made yet (the dry-row path of the loop looks at the descriptors of both sets)
         LV32(dma_a + DS_RQD * 256u + lane * 4u) = 0u;
         LV32(dma_a + (DS_RQ_SET + DS_RQD) * 256u + lane * 4u) = 0u;
@@ -1470,7 +1470,20 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                           \
             "v_cndmask_b32_e64 %[w2], %[w2], v101, s[36:37]\n\t"                                                          \
             ROWS_DRY_HITS
-#define ROWS_DRY_HANDLER                                                                                                     \
+// (SBIAS / SNBIAS: the format's window bias and its negation; LOGH: formats B and C leave the upper bits of the accepted candidate's local
+// row beside the long-form log word, as the C++ path does)
+#define ROWS_DRY_LOGH                                                                                                        \
+            "ds_read_b32 v124, %[ringa] offset:1280\n\t"               /* SY_TICK: its parity names the tick's log buffer */ \
+            "v_bfe_u32 v125, %[zn], 8, 2\n\t"                                                                           \
+            "v_bfe_u32 v126, %[zn], 11, 7\n\t"                                                                          \
+            "v_lshl_or_b32 v125, v126, 2, v125\n\t"                    /* rows_loc_hi(key) */                          \
+            "s_lshl_b32 s42, %[it], 1\n\t"                                                                              \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+            "v_and_b32 v124, 1, v124\n\t"                                                                               \
+            "v_lshl_add_u32 v124, v124, 5, %[ringa]\n\t"                                                                \
+            "v_add_u32 v124, s42, v124\n\t"                                                                             \
+            "ds_write_b16 v124, v125 offset:1408\n\t"                  /* RO_LOGH + 32 x parity + 2 x it */
+#define ROWS_DRY_HANDLER(SBIAS, SNBIAS, LOGH)                                                                                \
             "51:\n\t"                                                                                                     \
             "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
             "v_mov_b32 %[zz], %[zn]\n\t"                                                                                  \
@@ -1521,8 +1534,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_add_u32 v127, v127, %[li4]\n\t"                                                                            \
             "v_and_or_b32 v126, v127, v115, %[ringa]\n\t"                                                                 \
             ROWS_DRY_CANDIDATES                                                                                            \
-            "v_cmp_lt_u32_e32 vcc, 0x8000, %[w2]\n\t"                    /* the window's bias (rows_bias) */             \
-            "v_add_u32 v122, 0xffff8000, %[w2]\n\t"                                                                       \
+            "v_cmp_lt_u32_e32 vcc, " SBIAS ", %[w2]\n\t"                 /* the window's bias (rows_bias) */             \
+            "v_add_u32 v122, " SNBIAS ", %[w2]\n\t"                                                                       \
             "v_mov_b32 v125, 0x200\n\t"                                  /* ROWS_NEVER (a literal and vcc do not share the constant bus) */ \
             "s_nop 0\n\t"                                                                                                 \
             "v_cndmask_b32_e32 v122, v125, v122, vcc\n\t"                                                                 \
@@ -1559,6 +1572,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_min_u32 v126, 8, v126\n\t"                                /* candidates behind it (of the sector's) that become the window */ \
             "v_add3_u32 v126, %[e], v125, v126\n\t"                                                                       \
             "ds_write_b32 v123, v126\n\t"                                /* land = the position behind the window */     \
+            LOGH                                                                                                           \
             "v_add_u32 %[ndry], 1, %[ndry]\n\t"                                                                           \
             "s_mov_b64 exec, %[live]\n\t"                                                                                 \
             "ds_write_b32 %[tt], %[d]\n\t"                               /* the rows with a clear accept: shifted; the dry rows: emptied (every lane's slot: the all-ones key) */ \
@@ -1715,19 +1729,30 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                       rows_format(OFFSIM_STREAMS_B).amb == 0xfffd0000u && (rows_format(OFFSIM_STREAMS_B).emask | 0x400u) == 0x3c00ff00u, "the literals of the format-B loop");
         static_assert(rows_format(OFFSIM_STREAMS_C).paymask == 0x3ffffu && rows_format(OFFSIM_STREAMS_C).zmask == 0x4ffu &&
                       rows_format(OFFSIM_STREAMS_C).amb == 0xfff40000u && (rows_format(OFFSIM_STREAMS_C).emask | 0x400u) == 0x3c03ff00u, "the literals of the format-C loop");
+        static_assert(RO_SYNC - RO_RING == 1280u && SY_TICK == 0 && RO_LOGH - RO_RING == 1408u && rows_format(OFFSIM_STREAMS_B).bias == 0x20000u &&
+                      rows_format(OFFSIM_STREAMS_C).bias == 0x80000u, "immediates of the dry-row handler");
+#if defined(ROWS_NO_DRY_ASM) || defined(ROWS_NO_DRY_ASM_BC)
         if constexpr (fmt_c) {
             ROWS_FAST_ASM("0x3ffff", "0x4ff", "0xfff40000", "0x3c03ff00", "6", "");
         } else if constexpr (fmt_b) {
             ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
         } else {
+#else
+        if constexpr (fmt_c) {
+            ROWS_FAST_ASM("0x3ffff", "0x4ff", "0xfff40000", "0x3c03ff00", "5", ROWS_DRY_HANDLER("0x80000", "0xfff80000", ROWS_DRY_LOGH));
+        } else if constexpr (fmt_b) {
+            ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "5", ROWS_DRY_HANDLER("0x20000", "0xfffe0000", ROWS_DRY_LOGH));
+        } else {
+#endif
 #if defined(ROWS_NO_DRY_ASM) || (defined(ROWS_DRY_STAGE) && ROWS_LAND_LAG != 2)  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "6", "");
 #else
-            ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER);
+            ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER("0x8000", "0xffff8000", ""));
 #endif
         }
 #undef ROWS_FAST_ASM
 #undef ROWS_DRY_HANDLER
+#undef ROWS_DRY_LOGH
 #undef ROWS_STEP
 #undef ROWS_EPI
 #undef ROWS_OUT_A
