@@ -1761,11 +1761,18 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
+    // Entries a window must lack before the helper asks for its top-up (scan_rows.hpp, request()): 2 when the launch fills the device
+    // -- a third fewer requests in flight is what lets them land within one tick -- and 1 when a quarter of the CUs or more stay idle
+    // (measured at 10 M rows: 512 / 1024 / 2048 / 3072 rollouts ...).  OFFSIM_ROWS_MINROOM overrides (A/B runs).
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int minroom_env = getenv("OFFSIM_ROWS_MINROOM") ? atoi(getenv("OFFSIM_ROWS_MINROOM")) : 0;
+    const uint32_t rq_minroom = minroom_env > 0 ? (uint32_t)minroom_env : (int64_t)grid.x * 4 <= (int64_t)cus * 3 ? 1u : 2u;
 #define LAUNCH_ROWS(TR, HL, FMT, THREADS)                                                                                          \
     do {                                                                                                                           \
         HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT>), 160 * 1024));                                                          \
         hipLaunchKernelGGL((k_eval_mc_rows<TR, HL, FMT>), grid, dim3((unsigned)(THREADS)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, \
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region);                                                    \
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region, rq_minroom);                                        \
     } while (0)
     if (sm->format == OFFSIM_STREAMS_B) {
         if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_B, waves * 64);

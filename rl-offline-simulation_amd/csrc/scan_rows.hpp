@@ -112,16 +112,17 @@ __device__ __forceinline__ RowsRq rows_rq(bool second) {
     const uint32_t o = second ? DS_RQ_SET * 256u : 0u;
     return RowsRq{o + DS_RQA * 256u, o + DS_RQB * 256u, o + DS_RQD * 256u, o + DS_RQS * 256u};
 }
-// Ticks between a request round and the landing of what it asked for.  1 (rounds 2 and 3): the requests of tick t's steps land at the
-// end of tick t + 1 -- one tick period minus the helper's ~1000 cycles, ~2.5 us at the round-4 loop, which 8 % of the loads on
-// the XCDs with the longer memory latency no longer make (a top-up that is late is a top-up lost: 50 % more dry windows there, and the
-// kernel ends with its slowest workgroup).  2: two sets of request areas used in turn, a round lands two ticks later (~5.4 us).
+// Ticks between a request round and the landing of what it asked for.  1: the requests of tick t's steps land at the end of tick
+// t + 1 -- one tick period minus the helper's ~1000 cycles, ~2.5 us at the round-4 loop.  2: two sets of request areas used in turn, a
+// round lands two ticks later (~5.4 us).  Which one wins depends on how many requests are in flight: with a request for
+// every entry a window lacks (rq_minroom 1) 8 % of the loads on the XCDs with the longer memory latency missed a one-tick landing at
+// 4096 rollouts -- a top-up that is late is a top-up lost, 50 % more dry windows there, and the kernel ends with its slowest workgroup
+// -- and lag 2 was the faster kernel (1.02 s against 1.04); with no request for a single entry (rq_minroom 2: a third fewer requests)
+// 0.3 % are late at lag 1, on every XCD alike, and the windows are fuller when they are looked at: 0.930 s against 0.975 s.
 #ifndef ROWS_LAND_LAG
-#define ROWS_LAND_LAG 2
+#define ROWS_LAND_LAG 1
 #endif
-#ifndef ROWS_RQ_MINROOM
-#define ROWS_RQ_MINROOM 2u
-#endif
+// entries a window must lack before it is topped up: a kernel argument (rq_minroom), chosen by the launcher from the load (below)
 #ifndef ROWS_RQ_MAX
 #define ROWS_RQ_MAX 8u  // entries a top-up asks for at most (4: the second request area stays unused)
 #endif
@@ -230,7 +231,7 @@ template <bool TRACE, bool HELPER, int FMT>
 __global__ void __launch_bounds__(HELPER ? 512 : 256)
     k_eval_mc_rows(offsim_table t, offsim_rollouts ro, offsim_streams sm, const uint64_t *__restrict__ keys, double gamma,
                    const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out,
-                   uint32_t seg_bytes, uint32_t region_bytes) {
+                   uint32_t seg_bytes, uint32_t region_bytes, uint32_t rq_minroom) {
     static_assert(!(TRACE && HELPER), "the TRACE build is the single-wavefront kernel");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -749,10 +750,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         const uint32_t left = len - ld;
         uint32_t want = room < left ? room : left;
         want = want < ROWS_RQ_MAX ? want : ROWS_RQ_MAX;
-        // No top-up while the window lacks a single entry: a request costs a whole 128-byte line of fabric traffic whatever it asks
-        // for, and one entry more or less rarely decides whether a window runs dry (measured at 10 M x 4096: a third fewer
-        // requests, 37 k -> 48 k dry rows per rollout, kernel 0.988 -> 0.974 s; from three entries up the dry rows win: 1.05 s).
-        if (room < ROWS_RQ_MINROOM) want = 0u;
+        // No top-up while the window lacks a single entry (rq_minroom 2, what the launcher passes when every CU is busy): a request costs a
+        // whole 128-byte line of fabric traffic whatever it asks for, and one entry more or less rarely decides whether a window runs
+        // dry; a third fewer requests is what lets a one-tick landing arrive in time (ROWS_LAND_LAG).  From three entries up the dry
+        // rows win (lag 1: 0.975 s at 3, 1.07 s at 4, against 0.930 s).  With a quarter of the CUs idle or more, every entry is asked for.
+        if (room < rq_minroom) want = 0u;
         // (every lane issues the loads -- one that asks for nothing reads the rollout's own stream state into its slot, which
         // nobody looks at: a round then issues a fixed number of vector-memory instructions, ROWS_VM_REQ)
         const bool ok = mine && cl == li && want && (int64_t)beg + ld + 8 <= t.N;
