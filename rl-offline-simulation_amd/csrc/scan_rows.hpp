@@ -155,12 +155,14 @@ __host__ __device__ constexpr RowsFormat rows_format(int fmt) {  // (the format 
 __device__ __forceinline__ uint32_t rows_loc_hi(uint32_t pay) { return ((pay >> 8) & 3u) | (((pay >> 11) & 0x7fu) << 2); }
 
 // Cache policy of the reward pipeline's loads (local row of a served candidate, its reward; one dword out of a sector that is not
-// looked at again): NON-TEMPORAL.  With the default policy these 128 B per accepted step pass through L2 and push out the digest
-// sectors the window top-ups and the dry-row reads come back to; measured at 10 M x 4096 (tools/clock_rows.py): the XCDs with the
-// longer memory latency ran at 477 cycles per iteration against 453 on the others and the kernel ends with its slowest workgroup
-// -- with nt all eight run at 457, kernel 1.022 -> 0.990 s.  (nt on the digest requests themselves: 550 cycles per iteration.)
+// looked at again).  Which one is right depends on the top-up regime: with a two-tick landing and a request for every
+// missing entry, " nt" took the kernel from 1.022 to 0.990 s (with the default policy these 128 B per accepted step pushed the digest
+// sectors out of L2 on the XCDs with the longer memory latency: 477 cycles per iteration there against 453 on the others); with the
+// one-tick landing and a third fewer requests of the final kernel the DEFAULT policy is the faster one, 0.932 -> 0.903 s (a
+// non-temporal load takes longer to return, the helper's round gets longer, 13 k instead of 2 k top-ups per rollout arrive late).
+// (nt on the digest requests themselves: 550 cycles per iteration.)
 #ifndef ROWS_RW_CACHE
-#define ROWS_RW_CACHE " nt"
+#define ROWS_RW_CACHE ""
 #endif
 __device__ __forceinline__ void lds_dma_dword(const void *gptr, uint32_t lds_dst_uniform) {
     uint32_t keep;
@@ -1331,9 +1333,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #else
 #define ROWS_DRY_T1
 #endif
-#ifdef ROWS_DRY_WHOLE16  /* (A/B build: sixteen candidates whatever the sector) */
+#ifndef ROWS_DRY_IN_SECTOR  /* sixteen candidates whatever the sector (0.903 -> 0.900 s; with non-temporal reward loads it was the other way round) */
 #define ROWS_DRY_SECTOR "v_mov_b32 v121, 16\n\t"
-#else
+#else  /* (A/B build: only the candidates up to the end of the queue head's 64-byte sector) */
 #define ROWS_DRY_SECTOR
 #endif
 // The candidates of a dry row.  Default: straight from the stream.  ROWS_DRY_STAGE (experiment, off): first a look into the request
