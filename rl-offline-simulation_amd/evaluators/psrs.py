@@ -66,6 +66,10 @@ def stream_format(table):
     return L.STREAMS_B
 
 
+ROWS_TICK_STEPS = 16  # steps between two top-up rounds of the row-packed scan (csrc/scan_rows.hpp: ROWS_TICK)
+ROWS_MAX_WINDOW_LOAD = 1.2  # candidates a tick takes out of the busiest 8-entry window, above which the window kernel is the faster scan
+
+
 def _prob_mode(table, p_dtype):
     f32 = (p_dtype in (np.float32, torch.float32, np.dtype(np.float32))) and table.p_log.dtype == torch.float32
     return L.PROB_F32 if f32 else L.PROB_F64
@@ -205,21 +209,23 @@ class BatchedPSRS:
         p = policy if isinstance(policy, torch.Tensor) else np.asarray(policy)
         f64 = p.dtype in (torch.float64, np.float64, np.dtype(np.float64))
         # Which scan: the row-packed kernel tops a state's 8-entry window up once per tick of 16 steps, the window kernel (one rollout
-        # per wavefront, csrc/scan_win.hpp) refills on the spot.  A window that runs dry makes an exact-path iteration of the whole
-        # wavefront, and it runs dry when its state is visited more often than it can be topped up (a hot state) or when a look
-        # rejects all eight entries (probability (1 - acceptance)^8).  Measured (10 M rows, equal states, scan seconds per
-        # pass, row-packed / window kernel): 162 states at acceptance 0.54: 1.01 / 1.75, 0.38: 1.20 / 1.17, 0.29: 1.46 / 1.18, 0.24:
-        # 1.61 / 1.18; acceptance 0.54 with 50 states (2 % of the rows each): 1.23 / 1.42, 35: 1.39 / 1.41, 25: 1.62 / 1.41, 12: 2.54 / 1.43.
-        # So: the row-packed kernel when no state holds more than 3 % of the rows AND the policy's acceptance is at least 0.4.
+        # per wavefront, csrc/scan_win.hpp) refills on the spot.  A row whose window gives no clear accept -- dry, or every entry rejected --
+        # costs the whole wavefront a trip to memory, and how often that happens is a matter of how many candidates a tick takes out of
+        # the busiest window: 16 steps x (share of the steps that visit the state = its share of the rows) / acceptance.  Measured at the
+        # end of round 4 (tools/sweep_kernel_choice.sh, profiles/r04_kernel_choice_sweep.txt; 10 M rows, equal states, 1024 rollouts,
+        # scan + reset seconds per pass, row-packed / window kernel), with that load L in brackets:
+        #   162 states, acceptance 0.54 [0.18]: 0.98 / 1.40    0.38 [0.26]: 1.03 / 1.33    0.29 [0.34]: 1.15 / 1.34    0.24 [0.40]: 1.21 / 1.33
+        #   acceptance 0.54, 50 states [0.59]: 1.21 / 1.52    35 [0.85]: 1.32 / 1.52    25 [1.19]: 1.50 / 1.53    12 [2.5]: 2.08 / 1.57
+        #   50 states at 0.24 [1.31]: 1.45 / 0.78    25 states at 0.38 [1.71]: 1.69 / 1.13
+        # So: the row-packed kernel while L < 1.2.  (Round 3's rule -- no state above 3 % of the rows AND acceptance >= 0.4 -- was fitted
+        # to a kernel whose dry rows went through the C++ path; with the in-loop handler a low acceptance alone no longer decides.)
         # OFFSIM_SCAN_ROWS = 1 / 0 forces the one or the other.
         mode = os.environ.get("OFFSIM_SCAN_ROWS", "auto")
         ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
               and mode != "0")
         if not ok or mode == "1":
             return ok
-        if t.max_seg * 33 > t.N:  # some state holds more than 3 % of the rows
-            return False
-        return self._acceptance(policy) >= 0.4
+        return ROWS_TICK_STEPS * (t.max_seg / max(t.N, 1)) / max(self._acceptance(policy), 1e-9) < ROWS_MAX_WINDOW_LOAD
 
     def _acceptance(self, policy):
         """Acceptance probability of a candidate under `policy`, averaged over the table's rows: the mean of the compiled thresholds'

@@ -400,9 +400,10 @@ assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
 
 
 def test_scan_kernel_is_chosen_by_the_table(gpu):
-    """BatchedPSRS._streams_apply without OFFSIM_SCAN_ROWS: a table whose largest state holds more than 3 % of the rows, or a policy whose
-    acceptance is below 0.4, takes the window kernel on permutations, otherwise the row-packed kernel on streams; all give the oracle's results (child process:
-    the suite itself forces the row-packed kernel, tests/conftest.py)."""
+    """BatchedPSRS._streams_apply without OFFSIM_SCAN_ROWS: a table in which a tick of 16 steps takes more than 1.2 candidates out of its
+    busiest window (16 x the largest state's share of the rows / the policy's acceptance) takes the window kernel on permutations, otherwise
+    the row-packed kernel on streams; all give the oracle's results (child process: the suite itself forces the row-packed kernel,
+    tests/conftest.py)."""
     import os, subprocess, sys
     code = r'''
 import os, sys
@@ -413,7 +414,8 @@ from rl_offline_simulation_amd import synth
 from rl_offline_simulation_amd.table import TransitionTable
 from rl_offline_simulation_amd.evaluators import BatchedPSRS
 assert "OFFSIM_SCAN_ROWS" not in os.environ
-for nS, nA, want in ((10, 2, "k_eval_mc_win"), (120, 2, "k_eval_mc_rows"), (120, 5, "k_eval_mc_win")):  # a hot state; neither; low acceptance
+# a hot state; neither; low acceptance alone (round 3's rule took the window kernel here); low acceptance AND rather few states
+for nS, nA, want in ((10, 2, "k_eval_mc_win"), (120, 2, "k_eval_mc_rows"), (120, 5, "k_eval_mc_rows"), (40, 5, "k_eval_mc_win")):
     e = synth.synth_iid(60000, nS, nA, seed=nS)
     t0 = e["steps"] == 0
     table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
