@@ -1763,7 +1763,8 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
     // Entries a window must lack before the helper asks for its top-up (scan_rows.hpp, request()): 2 when the launch fills the device
     // -- a third fewer requests in flight is what lets them land within one tick -- and 1 when a quarter of the CUs or more stay idle
-    // (measured at 10 M rows: 512 / 1024 / 2048 / 3072 rollouts ...).  OFFSIM_ROWS_MINROOM overrides (A/B runs).
+    // (measured at 10 M rows, scan seconds with 1 / 2: 512 rollouts 0.840 / 0.865, 3072: 0.855 / 0.881, 3584: 0.895 / 0.917, 4096: 1.074 /
+    // 0.899: the cliff is at the full device).  OFFSIM_ROWS_MINROOM overrides (A/B runs).
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     static const int minroom_env = getenv("OFFSIM_ROWS_MINROOM") ? atoi(getenv("OFFSIM_ROWS_MINROOM")) : 0;
