@@ -1951,10 +1951,16 @@ static int launch_mlp_mfma(const XT *x, int64_t N, int dO, const float *W1, cons
         unsigned nb = (unsigned)((groups + 3) / 4);
         if (nb > 256) nb = 256;  // one workgroup (a wavefront per SIMD) per CU
         if (nb < 1) nb = 1;
+        // OFFSIM_ENCODER_F32=1: the exact-f32 products (round 3's kernel); default: the same kernel on bf16 x 3 (encode_mfma.hpp)
+        static const bool f32_products = getenv("OFFSIM_ENCODER_F32") && atoi(getenv("OFFSIM_ENCODER_F32")) != 0;
 #define LAUNCH_REG(DOc, HTc, ZTc, WPEc)                                                                                                \
     do {                                                                                                                               \
-        hipLaunchKernelGGL((k_encode_mlp_mfma_reg<XT, DOc, HTc, ZTc, WPEc>), dim3(nb * WPEc), dim3(256), 0, st, x, N, W1, b1, H, W2, b2, nZ, out_z, \
-                           out_logits);                                                                                                \
+        if (f32_products)                                                                                                              \
+            hipLaunchKernelGGL((k_encode_mlp_mfma_reg<XT, DOc, HTc, ZTc, WPEc>), dim3(nb * WPEc), dim3(256), 0, st, x, N, W1, b1, H, W2, b2, nZ, \
+                               out_z, out_logits);                                                                                     \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((k_encode_mlp_mfma_split<XT, DOc, HTc, ZTc, WPEc>), dim3(nb * WPEc), dim3(256), 0, st, x, N, W1, b1, H, W2, b2, nZ, \
+                               out_z, out_logits);                                                                                     \
         LAUNCH_CHECK();                                                                                                                \
         return OFFSIM_OK;                                                                                                              \
     } while (0)

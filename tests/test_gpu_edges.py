@@ -170,6 +170,7 @@ def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
     env = dict(os.environ)
     if variant == "win":
         env["OFFSIM_SCAN_ROWS"] = "0"
+        env["OFFSIM_ENCODER_F32"] = "1"  # (and the encoder's exact-f32 products, csrc/encode_mfma.hpp: the other members run it on bf16 x 3)
     elif variant == "auto":
         env["OFFSIM_SCAN_ROWS"] = "auto"
     else:
