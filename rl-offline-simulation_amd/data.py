@@ -69,8 +69,9 @@ class OfflineDataset:
     # ---- ingestion formats ----
     # The reference stores datasets as HDF5: one gzip dataset per experience key, the spaces and the
     # ProbDistribution pickled into group attributes (data.py:85-98, 120-146).  h5py is not part of this stack, so
-    # the native container here is .npz with the same keys and the spaces described in JSON (nothing is unpickled on
-    # load); HDF5 files written by the reference load through load_hdf5 wherever h5py is importable.
+    # the container this package WRITES is .npz with the same keys and the spaces described in JSON (nothing is
+    # unpickled on load); HDF5 files written by the reference load through load_hdf5 -- with h5py where it is
+    # importable, with the package's own reader of that subset of the format (hdf5.py) where it is not.
     def save_npz(self, path):
         meta = json.dumps({"observation_space": _space_to_json(self.observation_space), "action_space": _space_to_json(self.action_space),
                            "action_dist_type": ProbDistribution(self.action_dist_type).name})
@@ -84,16 +85,28 @@ class OfflineDataset:
                        ProbDistribution[meta["action_dist_type"]], **{k: z[k] for k in z.files if k != "__spaces__"})
 
     @classmethod
-    def load_hdf5(cls, path, group_name=None):
+    def load_hdf5(cls, path, group_name=None, reader=None):
         """data.py:81-83 / HDF5Dataset (data.py:120-146): arrays are read into memory (the device table copies them anyway).
         The `infos/<key>` datasets written by record_dataset_in_memory (utils/dataset_utils.py:83-113) come back as experience
-        keys "infos/<key>".  The pickled gym.spaces attributes are decoded by a restricted unpickler onto spaces.Discrete / Box."""
-        try:
-            import h5py
-        except ImportError as e:  # pragma: no cover - h5py is absent from the build image
-            raise ImportError("load_hdf5 needs h5py; convert with the reference's tools or use save_npz/load_npz") from e
-        with h5py.File(path, "r") as fin:
-            group = fin[group_name] if group_name else fin
+        keys "infos/<key>" (the reference's own HDF5Dataset trips over that group -- it validates `len(group)` against the number of
+        rows -- and reads such files through utils/dataset_utils.py:26-34 instead; here one loader serves both).  The pickled
+        gym.spaces attributes are decoded by a restricted unpickler onto spaces.Discrete / Box.
+        `reader`: "h5py", "native" (this package's own reader, hdf5.py: the subset of the format such files use, NumPy + zlib), or
+        None = h5py where it is importable, the native reader otherwise.  As in the reference (data.py:123) a `group_name` the file
+        does not hold falls back on the root group."""
+        if reader not in (None, "h5py", "native"):
+            raise ValueError(f"unknown HDF5 reader {reader!r}")
+        mod = None
+        if reader != "native":
+            try:
+                import h5py as mod
+            except ImportError:
+                if reader == "h5py":
+                    raise
+        if mod is None:
+            from . import hdf5 as mod
+        with mod.File(path, "r") as fin:
+            group = fin.get(group_name, default=fin) if group_name else fin
             return cls.from_hdf5_group(group)
 
     @classmethod

@@ -1,0 +1,247 @@
+"""SURVEY 8 f.2 -- the HDF5 ingestion format, pinned on files the REFERENCE'S OWN writer produced.
+
+tests/golden/hdf5/*.hdf5 were written by offsim4rl/data.py:85-98 (`OfflineDataset.save_hdf5`) running on a real h5py 3.3.0 / libhdf5 1.10.6
+(tests/golden/make_hdf5_golden.py, under the image's side interpreter -- the interpreter that runs the engine has no h5py), the
+`.expected.npz` beside each holds what the reference's own loader read back from it.  The product reads them with its own reader
+(rl-offline-simulation_amd/hdf5.py).  CPU only, except the last test (ingest -> device table -> evaluation against the oracle)."""
+import os
+import pickle
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+H5 = os.path.join(GOLDEN, "hdf5")
+SIDE_PY = "/opt/conda/bin/python3.9"
+
+
+def _expected(name):
+    with np.load(os.path.join(H5, name + ".expected.npz")) as z:
+        return {k.replace("__", "/"): z[k] for k in z.files}
+
+
+def _same(got, want):
+    assert sorted(got) == sorted(want)
+    for k in want:
+        a = np.asarray(got[k])
+        assert a.dtype == want[k].dtype and a.shape == want[k].shape and np.array_equal(a, want[k]), k
+
+
+@pytest.mark.parametrize("name, group", [("ref_test_data_discrete", None), ("ref_test_data_no_dist", None),
+                                         ("cartpole_like_3k_infos", None), ("cartpole_like_10k_group", "train")])
+def test_files_written_by_the_reference_load_with_the_native_reader(name, group):
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces
+    ds = OfflineDataset.load_hdf5(os.path.join(H5, name + ".hdf5"), group, reader="native")
+    _same(ds.experience, _expected(name))
+    assert ds.action_dist_type is (ProbDistribution.NoProbability if name.endswith("no_dist") else ProbDistribution.Discrete)
+    assert spaces.is_discrete(ds.action_space) and ds.action_space.n == (4 if name.startswith("ref_") else 2)
+    box = ds.observation_space
+    assert box.shape == ((1,) if name.startswith("ref_") else (4,)) and np.dtype(box.dtype) == np.float32
+    if name.startswith("ref_"):
+        assert np.array_equal(box.low, [0.0]) and np.array_equal(box.high, [1.0])
+    else:
+        assert np.array_equal(box.high, np.array([4.8, np.finfo(np.float32).max, 0.42, np.finfo(np.float32).max], np.float32))
+        assert np.array_equal(box.low, -box.high)
+
+
+def test_the_assertions_of_the_references_own_round_trip_test():
+    """tests/test_data.py:11-62 of the reference, second half: what `load_hdf5` must give back for the file its first half saved."""
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, spaces
+    ds = OfflineDataset.load_hdf5(os.path.join(H5, "ref_test_data_discrete.hdf5"))
+    assert spaces.Discrete(4) == ds.action_space and ProbDistribution.Discrete == ds.action_dist_type
+    e = ds.experience
+    assert np.array_equal(np.array([[0.0], [0.5]], dtype=np.float32), e["observations"])
+    assert np.array_equal(np.array([0, 1], dtype=np.int64), e["actions"])
+    assert np.array_equal(np.full((2, 4), fill_value=0.25, dtype=np.float32), e["action_distributions"])
+    assert np.array_equal(np.array([0.0, 1.0], dtype=np.float32), e["rewards"])
+    assert np.array_equal(np.array([[0.5], [0.0]], dtype=np.float32), e["next_observations"])
+    assert np.array_equal(np.array([False, True], dtype=bool), e["terminals"]) and e["terminals"].dtype == np.bool_
+    ds2 = OfflineDataset.load_hdf5(os.path.join(H5, "ref_test_data_no_dist.hdf5"))
+    assert ds2.action_dist_type is ProbDistribution.NoProbability and "action_distributions" not in ds2.experience
+    # data.py:123: a group name the file does not hold falls back on the root group
+    assert len(OfflineDataset.load_hdf5(os.path.join(H5, "ref_test_data_no_dist.hdf5"), "absent")) == 2
+    with pytest.raises(ValueError, match="Missing required key observations"):
+        OfflineDataset.load_hdf5(os.path.join(H5, "cartpole_like_10k_group.hdf5"))  # the root holds only the group "train"
+    with pytest.raises(ValueError):
+        OfflineDataset.load_hdf5(os.path.join(H5, "ref_test_data_no_dist.hdf5"), reader="pytables")
+
+
+def test_attribute_bytes_are_the_pickles_the_reference_stored():
+    """data.py:96-98 stores np.void(pickle.dumps(value)); data.py:143-146 reads `.tobytes()` back.  The opaque attribute must come
+    back byte for byte: pickle's STOP opcode ends it, the stream names gym.spaces.* / offsim4rl.data, and the restricted loader
+    maps them onto this package's types without importing either."""
+    from rl_offline_simulation_amd import hdf5
+    from rl_offline_simulation_amd.data import ProbDistribution, restricted_loads
+    with hdf5.File(os.path.join(H5, "cartpole_like_3k_infos.hdf5")) as f:
+        assert list(f.attrs) == ["observation_space", "action_space", "action_dist_type"]
+        raw = {k: f.attrs[k].tobytes() for k in f.attrs}
+    for k, b in raw.items():
+        assert b[:1] == b"\x80" and b[-1:] == b".", k
+    assert b"gym.spaces.box" in raw["observation_space"] and b"gym.spaces.discrete" in raw["action_space"]
+    assert b"offsim4rl.data" in raw["action_dist_type"]
+    assert restricted_loads(raw["action_dist_type"]) is ProbDistribution.Discrete
+    with pytest.raises(Exception):
+        pickle.loads(raw["observation_space"])  # plain pickle would import gym (absent here); nothing in the product does that
+
+
+def test_format_coverage_files_written_by_h5py():
+    """Straight h5py output (no reference code): two-level chunk B-trees, shuffle / fletcher32 / deflate, contiguous, big-endian, half,
+    the bool enum, scalars, empty datasets, fixed strings, nested groups, a multi-leaf group B-tree; the same under libver='latest'
+    (version-2 object headers, link messages) for the layouts that format shares."""
+    from rl_offline_simulation_amd import hdf5
+    with np.load(os.path.join(H5, "coverage.expected.npz")) as z:
+        want = {k: z[k] for k in z.files}
+    seen = set()
+    for fn in ("coverage_earliest.hdf5", "coverage_latest.hdf5"):
+        with hdf5.File(os.path.join(H5, fn)) as f:
+            for k in f:
+                if k in want:
+                    a, e = np.asarray(f[k]), want[k]
+                    assert f[k].shape == e.shape and f[k].dtype == e.dtype.newbyteorder("=")
+                    assert a.dtype == e.dtype.newbyteorder("=") and np.array_equal(a, e), (fn, k)
+                    seen.add(k)
+            assert f.attrs["i"] == 7 and f.attrs["i"].dtype == np.int64
+            assert np.array_equal(f.attrs["arr"], np.arange(5, dtype=np.float32))
+            assert f.attrs["blob"].tobytes() == b"\x00\x01\x02payload\xff" and f.attrs.get("absent", 5) == 5
+            assert np.array_equal(f["deep/er/x"][:], np.arange(6).reshape(2, 3)) and f["deep"]["er"].attrs["note"] == b"fixed"
+            assert f["/deep/er"].name == "/deep/er" and "deep/er/x" in f and "deep/nope" not in f and f.get("nope") is None
+            with pytest.raises(KeyError):
+                f["nope"]
+            assert f["scalar_f32"][()] == np.float32(2.5) and f["scalar_f32"].shape == ()
+            with pytest.raises(TypeError):
+                len(f["scalar_f32"])
+            assert len(f["contiguous_f64"]) == 777 and f["contiguous_f64"][5] == want["contiguous_f64"][5]
+            assert np.array_equal(f["contiguous_f64"][10:20], want["contiguous_f64"][10:20])
+            names = []
+            f.visititems(lambda n, o: names.append(n))  # h5py's traversal: every member, groups included, paths relative to the start
+            assert "deep" in names and "deep/er" in names and "deep/er/x" in names
+            assert f.visititems(lambda n, o: n if n.endswith("/x") else None) == "deep/er/x"
+            if "many_keys" in f:
+                mk = f["many_keys"]
+                assert len(mk) == 60 and list(mk) == [f"k{i:03d}" for i in range(60)]
+                assert all(np.array_equal(mk[f"k{i:03d}"][:], np.full(3, i)) for i in range(60))
+    assert seen == set(want)
+
+
+def test_what_the_reader_does_not_cover_is_refused_not_guessed(tmp_path):
+    from rl_offline_simulation_amd import hdf5
+    with hdf5.File(os.path.join(H5, "coverage_latest_chunked.hdf5")) as f:
+        assert f["x"].shape == (100,)  # header and dataspace are readable ...
+        with pytest.raises(NotImplementedError, match="version-4 chunk index"):
+            np.asarray(f["x"])  # ... the chunk index of libver='latest' is not
+    p = tmp_path / "not.hdf5"
+    p.write_bytes(b"PK\x03\x04" + bytes(4000))
+    with pytest.raises(hdf5.HDF5FormatError, match="not an HDF5 file"):
+        hdf5.File(p)
+    whole = open(os.path.join(H5, "cartpole_like_3k_infos.hdf5"), "rb").read()
+    q = tmp_path / "cut.hdf5"
+    q.write_bytes(whole[: len(whole) // 2])
+    with pytest.raises(hdf5.HDF5FormatError, match="past the end"):
+        with hdf5.File(q) as f:
+            f.visititems(lambda n, o: np.asarray(o) if isinstance(o, hdf5.Dataset) else None)
+    with pytest.raises(ValueError):
+        hdf5.File(os.path.join(H5, "ref_test_data_no_dist.hdf5"), "w")
+
+
+@pytest.mark.skipif(not os.path.exists(SIDE_PY), reason="no interpreter with h5py on this box")
+def test_random_files_from_a_real_h5py_read_back_equal(tmp_path):
+    """Fuzz against the real library where one is installed (the image's side interpreter): random shapes, dtypes, chunk shapes and
+    filter stacks written by h5py, read by the native reader."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, numpy as np, h5py\n"
+        "rng = np.random.default_rng(int(sys.argv[2]))\n"
+        "dts = ['f4', 'f8', 'f2', 'i8', 'i4', 'i2', 'i1', 'u1', 'u2', 'u4', 'u8', '?', '>f8', '>i2']\n"
+        "exp = {}\n"
+        "with h5py.File(sys.argv[1] + '.hdf5', 'w') as f:\n"
+        "    for i in range(24):\n"
+        "        rank = int(rng.integers(1, 4))\n"
+        "        shape = tuple(int(x) for x in rng.integers(0 if i % 7 == 0 else 1, [400, 9, 4][:rank]))\n"
+        "        dt = np.dtype(dts[int(rng.integers(len(dts)))])\n"
+        "        a = (rng.random(shape) < 0.5) if dt.kind == 'b' else (rng.integers(0, 100, shape).astype(dt))\n"
+        "        kw = {}\n"
+        "        mode = int(rng.integers(4))\n"
+        "        if mode and a.size:\n"
+        "            kw['chunks'] = tuple(int(rng.integers(1, max(2, s // 2 + 2))) for s in shape)\n"
+        "            if mode >= 2: kw['compression'] = 'gzip'; kw['compression_opts'] = int(rng.integers(1, 10))\n"
+        "            if mode == 3: kw['shuffle'] = True; kw['fletcher32'] = bool(rng.integers(2))\n"
+        "        g = f if i % 3 else f.require_group('sub/g%d' % (i % 2))\n"
+        "        g.create_dataset('d%d' % i, data=a, **kw)\n"
+        "        exp[(g.name.strip('/') + '/' if g.name != '/' else '') + 'd%d' % i] = a\n"
+        "    d = f.create_dataset('unwritten', shape=(50, 3), dtype='f4', chunks=(8, 3), fillvalue=1.5)\n"
+        "    d[8:16] = 2.0\n"
+        "    exp['unwritten'] = d[:]\n"
+        "np.savez(sys.argv[1] + '.npz', **{k.replace('/', '__'): v for k, v in exp.items()})\n")
+    from rl_offline_simulation_amd import hdf5
+    for seed in range(3):
+        base = str(tmp_path / f"fuzz{seed}")
+        subprocess.run([SIDE_PY, str(script), base, str(seed)], check=True, capture_output=True, env={"PATH": os.environ.get("PATH", "")})
+        with np.load(base + ".npz") as z:
+            want = {k.replace("__", "/"): z[k] for k in z.files}
+        got = {}
+        with hdf5.File(base + ".hdf5") as f:
+            f.visititems(lambda n, o: got.__setitem__(n, np.asarray(o)) if isinstance(o, hdf5.Dataset) else None)
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype.newbyteorder("=") and got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), (seed, k)
+
+
+@pytest.mark.gpu
+def test_a_log_stored_by_the_reference_goes_from_the_hdf5_file_to_the_device_and_evaluates_like_the_oracle():
+    """The ingestion row end to end: the file the reference's writer produced -> native reader -> OfflineDataset -> SoA table in HBM (the
+    `infos/z` column as the latent state) -> sampler reset + evalMC for 8 seeds, against the CPU oracle on the arrays the reference's
+    own loader read from the same file.  And through the facade: the evaluator built from the file serves the rows the evaluator built
+    from those arrays serves."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no CPU fallback exists)")
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import OfflineDataset, ProbDistribution, _lib, spaces
+    from rl_offline_simulation_amd.encoders import CartpoleBoxEncoder
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS, PerStateRejectionSampling
+    from rl_offline_simulation_amd.table import TransitionTable
+    _lib.load()
+    ds = OfflineDataset.load_hdf5(os.path.join(H5, "cartpole_like_3k_infos.hdf5"), reader="native")
+    want = _expected("cartpole_like_3k_infos")
+    e = ds.experience
+    z = np.asarray(e["infos/z"])
+    z_next = np.roll(z, -1)
+    t0 = np.asarray(e["steps"]) == 0
+    table = TransitionTable(z, e["actions"], e["rewards"], z_next, e["terminals"], e["action_distributions"], t0)
+    R = 8
+    env = BatchedPSRS(table, R)
+    pi = np.random.default_rng(5).dirichlet(np.ones(2), size=int(z.max()) + 1)
+    env.reset_sampler(list(range(R)))
+    out = env.eval_mc(table.policy_slots(pi), 0.99, trace_cap=len(z))
+    torch.cuda.synchronize()
+    ora = O.OraclePSRS(want["infos/z"], want["actions"], want["rewards"], np.roll(want["infos/z"], -1), want["terminals"],
+                       want["action_distributions"], want["steps"] == 0)
+    for i in range(R):
+        ora.reset_sampler(i)
+        ref = ora.evalmc(10 ** 9, pi, 0.99, trace_cap=len(z))
+        n = ref["steps"]
+        assert int(out["steps"][i]) == n and np.array_equal(out["trace_row"][i, :n].cpu().numpy(), ref["trace_rows"])
+        if len(ref["Gs"]):
+            assert abs(float(out["sum_g"][i]) / int(out["n_ep"][i]) - ref["Gs"].mean()) <= 1e-5
+    _lib.check_async_faults()
+    # facade: file -> evaluator, arrays -> evaluator
+    box = spaces.Box(low=-np.inf, high=np.inf, shape=(4,), dtype=np.float32)
+    ds2 = OfflineDataset(box, spaces.Discrete(2), ProbDistribution.Discrete, **{k: v for k, v in want.items() if not k.startswith("infos/")})
+    served = []
+    for d in (ds, ds2):
+        exp = {k: v for k, v in d.experience.items() if not k.startswith("infos/")}
+        d = OfflineDataset(d.observation_space, d.action_space, d.action_dist_type, **exp)
+        psrs = PerStateRejectionSampling(d, num_states=162, encoder=CartpoleBoxEncoder(), new_step_api=True)
+        psrs.reset_sampler(seed=3)
+        rows = []
+        obs = psrs.reset()
+        while obs is not None and len(rows) < 400:
+            o = psrs.step_dist(np.array([0.5, 0.5]))
+            if o[0] is None:
+                break
+            rows.append((psrs._impl._env.last_row, o[0], float(o[2]), bool(o[3])))
+            obs = psrs.reset() if o[3] else o[1]
+        served.append(rows)
+    assert len(served[0]) > 50 and served[0] == served[1]
