@@ -1749,26 +1749,34 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     int waves = 4;  // (the DMA areas of the workgroup are rounded up together: rows_dma_total)
     while (waves >= 1 && 1024u + seg_bytes + rows_dma_total((uint32_t)waves) + (uint32_t)waves * 4u * region > 160u * 1024u) waves--;
     if (waves < 1) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: LDS too small for this state count%s");
-#ifdef ROWS_EXPERIMENT_ISOLATE  // measurement build: two chain wavefronts + two helpers per CU (a workgroup that takes the CU's LDS alone), one wavefront per SIMD
-    waves = waves > 2 ? 2 : waves;
-#endif
-    const int rpb = waves * 4;
-#ifdef ROWS_EXPERIMENT_ISOLATE
-    const size_t lds = 100 * 1024;
-#else
-    const size_t lds = 1024 + seg_bytes + (size_t)rows_dma_total((uint32_t)waves) + (size_t)rpb * region;
-#endif
-    dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
+    // A launch that does not need every CU at four chain wavefronts each is SPREAD: as few chain wavefronts per workgroup as still fit
+    // the device in one wave of workgroups (512 rollouts: 128 workgroups of one chain wavefront + its helper, each alone on a CU, every
+    // wavefront on a SIMD of its own; 2048: two + two), the workgroup asking for more than half of the CU's LDS so that no two share a
+    // CU.  The kernel's time is the chain's latency whatever the number of rollouts, and a chain wavefront that shares neither its SIMD
+    // with a helper nor the LDS pipeline with three other pairs is the faster chain (the 8-rollouts-per-CU measurement build of round 3,
+    // ROWS_EXPERIMENT_ISOLATE: 428 against 461 cycles per iteration).  OFFSIM_ROWS_WAVES = 1..4 forces a shape (A/B runs, the variant matrix).
+    static const int waves_env = getenv("OFFSIM_ROWS_WAVES") ? atoi(getenv("OFFSIM_ROWS_WAVES")) : 0;
+    const int waves_fit = waves;
+    if (waves_env > 0) {
+        waves = waves_env < waves_fit ? waves_env : waves_fit;
+    } else if (helper && !trace) {
+        int w = (int)((ro->R + 4ll * cus - 1) / (4ll * cus));  // chain wavefronts per CU when the rollouts are dealt out evenly
+        waves = w < 1 ? 1 : w < waves_fit ? w : waves_fit;
+    }
+    const int rpb = waves * 4;
+    size_t lds = 1024 + seg_bytes + (size_t)rows_dma_total((uint32_t)waves) + (size_t)rpb * region;
+    if (waves < waves_fit && lds < 81u * 1024u) lds = 81u * 1024u;  // (a workgroup per CU)
+    dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // Entries a window must lack before the helper asks for its top-up (scan_rows.hpp, request()): 2 when the launch fills the device
     // -- a third fewer requests in flight is what lets them land within one tick -- and 1 when a quarter of the CUs or more stay idle
     // (measured at 10 M rows, scan seconds with 1 / 2: 512 rollouts 0.840 / 0.865, 3072: 0.855 / 0.881, 3584: 0.895 / 0.917, 4096: 1.074 /
     // 0.899: the cliff is at the full device).  OFFSIM_ROWS_MINROOM overrides (A/B runs).
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     static const int minroom_env = getenv("OFFSIM_ROWS_MINROOM") ? atoi(getenv("OFFSIM_ROWS_MINROOM")) : 0;
-    const uint32_t rq_minroom = minroom_env > 0 ? (uint32_t)minroom_env : (int64_t)grid.x * 4 <= (int64_t)cus * 3 ? 1u : 2u;
+    const uint32_t rq_minroom = minroom_env > 0 ? (uint32_t)minroom_env : (int64_t)ro->R <= 12ll * cus ? 1u : 2u;  // (rollouts, whatever the shape of the launch)
 #define LAUNCH_ROWS(TR, HL, FMT, THREADS)                                                                                          \
     do {                                                                                                                           \
         HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT>), 160 * 1024));                                                          \

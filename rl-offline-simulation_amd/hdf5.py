@@ -22,7 +22,8 @@ Refused with NotImplementedError, never guessed at: variable-length, compound, r
 
 The objects mimic the slice of h5py's API the reference touches: `File(path)` is a `Group`; groups have `.attrs`, `keys()`, iteration,
 `in`, `[name]` (paths with "/" allowed), `.get(name, default)`, `visititems(fn)`; datasets have `.shape`, `.dtype`, `len()`, `[...]` / `[()]`
-and convert with `np.asarray`.  Everything is read eagerly per dataset on first access (the device table copies the columns anyway).
+and convert with `np.asarray`.  A dataset is read whole on every access and comes back as a fresh, writable array, as with h5py (the
+device table copies the columns anyway).
 Format source: the HDF5 File Format Specification, version 3.0 (public; restated here, no code taken from libhdf5 or h5py).
 """
 import struct
@@ -404,7 +405,6 @@ class Dataset:
             raise _unsupported("a dataset with a null dataspace")
         self.dtype = np.dtype(np.bool_) if self._t.as_bool else self._t.dtype.newbyteorder("=") if self._t.dtype.kind in "iuf" else self._t.dtype
         self._attrs = None
-        self._cache = None
 
     @property
     def attrs(self):
@@ -426,8 +426,6 @@ class Dataset:
         return self.shape[0]
 
     def _read(self):
-        if self._cache is not None:
-            return self._cache
         f, h, t = self._f, self._h, self._t
         lay = _parse_layout(h.find(0x0008), f.osz, f.lsz)
         n = self.size
@@ -447,10 +445,10 @@ class Dataset:
                 flat = np.frombuffer(f.buf.bytes(f.base + lay.addr, n * t.size), dtype=t.dtype, count=n)
         else:
             flat = self._read_chunks(lay, fill)
-        self._cache = _finish(np.asarray(flat).reshape(self.shape), t)
-        if isinstance(self._cache, np.ndarray):
-            self._cache.setflags(write=False)
-        return self._cache
+        out = _finish(np.asarray(flat).reshape(self.shape), t)
+        if isinstance(out, np.ndarray) and not out.flags.writeable:
+            out = out.copy()  # (views of the file's bytes are read-only; h5py hands out fresh, writable arrays)
+        return out
 
     def _filled(self, n, fill):
         out = np.zeros(n, dtype=self._t.dtype)
@@ -510,12 +508,12 @@ class Dataset:
         return a if dtype is None else a.astype(dtype)
 
     def __getitem__(self, key):
-        a = self._read()
+        a = self._read()  # (the whole dataset, every time: nothing is cached, as with h5py)
         if isinstance(key, tuple) and key == ():
-            return a if not isinstance(a, np.ndarray) or a.ndim else a[()]
+            return a
         if not isinstance(a, np.ndarray):
             raise ValueError("Illegal slicing argument for scalar dataspace")
-        return np.array(a[key]) if isinstance(a[key], np.ndarray) else a[key]
+        return a[key]
 
     def __iter__(self):
         return iter(self._read())

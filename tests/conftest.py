@@ -17,6 +17,10 @@ def pytest_configure(config):
     # kernel -- and runs the window kernel through the variant matrix (test_gpu_edges.py) and the tests that switch to it; the automatic
     # choice has its own test (test_gpu_round3.py).
     os.environ.setdefault("OFFSIM_SCAN_ROWS", "1")
+    # Likewise the shape of its launch: the product spreads a launch of few rollouts over the CUs (one to three chain wavefronts per
+    # workgroup instead of four, offsim_eval_mc_streams), which is what every small test would get; the suite keeps the headline's shape
+    # (four chain wavefronts + four helpers per workgroup) and runs the others through the variant matrix and the "auto" member.
+    os.environ.setdefault("OFFSIM_ROWS_WAVES", "4")
 
 
 @pytest.fixture(scope="session")

