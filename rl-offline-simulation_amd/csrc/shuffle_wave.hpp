@@ -63,9 +63,6 @@ __device__ __forceinline__ void shuf_bound(volatile __attribute__((address_space
     if (__builtin_expect((++polls & 1023u) == 0u, 0)) shuf_bound_check(ctrl, polls);  // (out of line: the waits keep their shape)
 #endif
 }
-#ifndef SHUF_G_SLEEP
-#define SHUF_G_SLEEP 1  // units of 64 clocks between two polls of a G wavefront that waits for room in the draw ring (its polls are LDS reads too)
-#endif
 #define SHUF_CH 512u  // keyed emit: positions per chunk (one turn of a wavefront: 4 pairs per lane)
 
 // explicit LDS address space: keeps every ring / segment access a ds_* instruction (a generic pointer would make
@@ -253,7 +250,7 @@ __global__ void __launch_bounds__(256)
                         sh_st(ctrl + (g ? SH_EM1 : SH_EM0), (uint32_t)em_next);  // this parity is out from here up
                         em_next -= 2;
                     } else {
-                        __builtin_amdgcn_s_sleep(SHUF_G_SLEEP);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                     cpub = sh_ld(ctrl + SH_CPUB);
                 }
@@ -423,9 +420,6 @@ __global__ void __launch_bounds__(256)
                 if (fill - done < 64u) {
                     SPW0();
                     uint32_t polls = 0;
-#ifndef SHUF_TAIL_EVERY_GROUP
-                    sh_st(ctrl + SH_TAIL, done);  // (C may be waiting for exactly this room: publish before waiting for it)
-#endif
                     while (fill - done < 64u) {
                         fill = sh_ld(ctrl + SH_FILL);
                         if (fill - done < 64u) {
@@ -437,13 +431,7 @@ __global__ void __launch_bounds__(256)
                 }
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 done += 64u;
-                // issued after the read: the entries may be overwritten.  Every fourth group only (a store holds the wavefront for 16 cycles
-                // and the ring is 1024 / 4096 entries deep); what C sees is at most 192 entries behind, and exact whenever this wavefront waits.
-#ifdef SHUF_TAIL_EVERY_GROUP
-                sh_st(ctrl + SH_TAIL, done);
-#else
-                if ((done & 255u) == 0u) sh_st(ctrl + SH_TAIL, done);
-#endif
+                sh_st(ctrl + SH_TAIL, done);  // issued after the read: the entries may be overwritten
                 const uint32_t i_first = i_top;
                 const uint32_t il = i_first - (uint32_t)lane;
                 i_top -= 64u;
