@@ -26,6 +26,7 @@ and convert with `np.asarray`.  A dataset is read whole on every access and come
 device table copies the columns anyway).
 Format source: the HDF5 File Format Specification, version 3.0 (public; restated here, no code taken from libhdf5 or h5py).
 """
+import mmap
 import struct
 import zlib
 
@@ -296,6 +297,7 @@ class _Header:
         p += w
         blocks = [(p, size)]
         with_order = bool(flags & 0x04)
+        n_blocks = 0
         while blocks:
             p, n = blocks.pop(0)
             end = p + n
@@ -311,6 +313,9 @@ class _Header:
                     if buf.bytes(a, 4) != b"OCHK":
                         raise HDF5FormatError("object header continuation block without its signature")
                     blocks.append((a + 4, ln - 8))  # without signature and checksum
+                    n_blocks += 1
+                    if n_blocks > 4096:
+                        raise HDF5FormatError("object header continuation blocks do not end")
                 elif mtype != 0:
                     self.msgs.append((mtype, body))
 
@@ -640,16 +645,23 @@ class File(Group):
     def __init__(self, path, mode="r"):
         if mode != "r":
             raise ValueError("this reader opens files read-only")
-        with open(path, "rb") as fh:
-            data = fh.read()
-        self.buf = _Buf(memoryview(data))
+        # the file is mapped, not read: a big log costs its arrays once (contiguous datasets are copied out of the map, chunks inflated)
+        self._fh = open(path, "rb")
+        try:
+            self._map = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:  # an empty file cannot be mapped
+            self._fh.close()
+            raise HDF5FormatError(f"{path}: no HDF5 signature (not an HDF5 file)") from None
+        data = memoryview(self._map)
+        self.buf = _Buf(data)
         self.filename = str(path)
         self._objects = {}
         base = 0
         while True:
             if base + 8 > len(data):
+                self.close()
                 raise HDF5FormatError(f"{path}: no HDF5 signature (not an HDF5 file)")
-            if data[base:base + 8] == _SIG:
+            if bytes(data[base:base + 8]) == _SIG:
                 break
             base = 512 if base == 0 else base * 2
         buf = self.buf
@@ -744,7 +756,21 @@ class File(Group):
         yield from walk(btree)
 
     def close(self):
-        pass
+        """Unmaps the file.  Arrays already handed out are copies and stay valid; groups and datasets of a closed file are not."""
+        if self._map is not None:
+            self.buf = _Buf(b"")
+            try:
+                self._map.close()
+            except BufferError:  # (a view of the map is still referenced somewhere: the map goes with its last reference)
+                pass
+            self._map = None
+            self._fh.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self
