@@ -1753,22 +1753,32 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // OFFSIM_ROWS_HELPER=0 runs the single-wavefront form of the kernel (what the TRACE build always is)
     static const bool helper = !(getenv("OFFSIM_ROWS_HELPER") && atoi(getenv("OFFSIM_ROWS_HELPER")) == 0);
-    // A launch that does not need every CU at four chain wavefronts each is SPREAD: as few chain wavefronts per workgroup as still fit
-    // the device in one wave of workgroups (512 rollouts: 128 workgroups of one chain wavefront + its helper, each alone on a CU, every
-    // wavefront on a SIMD of its own; 2048: two + two), the workgroup asking for more than half of the CU's LDS so that no two share a
-    // CU.  The kernel's time is the chain's latency whatever the number of rollouts, and a chain wavefront that shares neither its SIMD
-    // with a helper nor the LDS pipeline with three other pairs is the faster chain (the 8-rollouts-per-CU measurement build of round 3,
-    // ROWS_EXPERIMENT_ISOLATE: 428 against 461 cycles per iteration).  OFFSIM_ROWS_WAVES = 1..4 forces a shape (A/B runs, the variant matrix).
+    // A launch that does not need every CU at four chain wavefronts of four rollouts each is SPREAD, in two ways (10 M rows, scan seconds,
+    // tools/sweep_launch_shape.sh and sweep_launch_shape2.sh, profiles/r04_launch_shape_sweep*.txt):
+    //  * as few chain wavefronts (+ helpers) per workgroup as still fit the device in one wave of workgroups, the workgroup asking for more
+    //    than half of the CU's LDS so that no two share a CU: the kernel's time is the chain's latency whatever the number of rollouts, and
+    //    a chain wavefront that shares neither its SIMD with a helper nor the LDS pipeline with three other pairs is the faster chain
+    //    (2048 rollouts: two pairs per CU 0.782 s, packed four to a CU 0.853 s);
+    //  * at four rollouts per CU or fewer, two rollouts to a chain wavefront instead of four (two of its rows left empty), at one per CU
+    //    one: every event of a row -- an episode end, a row without a clear accept -- holds its whole wavefront (1024 rollouts: 0.696 s
+    //    as two pairs of two against 0.745 as one pair of four; 512: 0.684 against 0.744; 256: 0.655 with one rollout per wavefront).
+    //    At eight per CU four pairs of two and two pairs of four are level (0.773 / 0.768): four rows stay.
+    // OFFSIM_ROWS_WAVES = 1..4 and OFFSIM_ROWS_PER_WAVE = 1 | 2 | 4 force a shape (A/B runs, the variant matrix of the test suite).
     static const int waves_env = getenv("OFFSIM_ROWS_WAVES") ? atoi(getenv("OFFSIM_ROWS_WAVES")) : 0;
+    static const int rpw_env = getenv("OFFSIM_ROWS_PER_WAVE") ? atoi(getenv("OFFSIM_ROWS_PER_WAVE")) : 0;
     const int waves_fit = waves;
+    int rpw = 4;
+    const bool rpw_forced = rpw_env == 1 || rpw_env == 2 || rpw_env == 4;
+    if (rpw_forced) rpw = rpw_env;
     if (waves_env > 0) {
         waves = waves_env < waves_fit ? waves_env : waves_fit;
     } else if (helper && !trace) {
-        int w = (int)((ro->R + 4ll * cus - 1) / (4ll * cus));  // chain wavefronts per CU when the rollouts are dealt out evenly
+        if (!rpw_forced) rpw = ro->R <= (int64_t)cus ? 1 : ro->R <= 4ll * cus ? 2 : 4;
+        int w = (int)((ro->R + (int64_t)rpw * cus - 1) / ((int64_t)rpw * cus));  // chain wavefronts per CU when the rollouts are dealt out evenly
         waves = w < 1 ? 1 : w < waves_fit ? w : waves_fit;
     }
-    const int rpb = waves * 4;
-    size_t lds = 1024 + seg_bytes + (size_t)rows_dma_total((uint32_t)waves) + (size_t)rpb * region;
+    const int rpb = waves * rpw;  // rollouts per workgroup (its LDS holds four regions per chain wavefront whatever their use)
+    size_t lds = 1024 + seg_bytes + (size_t)rows_dma_total((uint32_t)waves) + (size_t)waves * 4u * region;
     if (waves < waves_fit && lds < 81u * 1024u) lds = 81u * 1024u;  // (a workgroup per CU)
     dim3 grid((unsigned)((ro->R + rpb - 1) / rpb));
     // Entries a window must lack before the helper asks for its top-up (scan_rows.hpp, request()): 2 when the launch fills the device
@@ -1781,7 +1791,7 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     do {                                                                                                                           \
         HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT>), 160 * 1024));                                                          \
         hipLaunchKernelGGL((k_eval_mc_rows<TR, HL, FMT>), grid, dim3((unsigned)(THREADS)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, \
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region, rq_minroom);                                        \
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region, rq_minroom, (uint32_t)rpw);                                        \
     } while (0)
     if (sm->format == OFFSIM_STREAMS_B) {
         if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_B, waves * 64);

@@ -233,7 +233,7 @@ template <bool TRACE, bool HELPER, int FMT>
 __global__ void __launch_bounds__(HELPER ? 512 : 256)
     k_eval_mc_rows(offsim_table t, offsim_rollouts ro, offsim_streams sm, const uint64_t *__restrict__ keys, double gamma,
                    const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out,
-                   uint32_t seg_bytes, uint32_t region_bytes, uint32_t rq_minroom) {
+                   uint32_t seg_bytes, uint32_t region_bytes, uint32_t rq_minroom, uint32_t rows_used) {
     static_assert(!(TRACE && HELPER), "the TRACE build is the single-wavefront kernel");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -248,9 +248,11 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const uint32_t lds_pad = (0u - lds_base) & 1023u;
     const uint32_t seg_a = lds_base + lds_pad;  // seg_off copy, shared by the block
     for (uint32_t i = threadIdx.x; i <= n_slots; i += blockDim.x) LV32(seg_a + i * 4u) = t.seg_off[i];
-    const uint32_t rpb = n_chain * 4u;  // rollouts per block
-    const uint32_t rid = wave * 4u + rw;
-    const int64_t r = (int64_t)blockIdx.x * rpb + rid;
+    // rows_used (4, 2 or 1): the rows of a wavefront that carry a rollout.  A sparse launch leaves rows empty on purpose (the launcher,
+    // offsim_eval_mc_streams): every event of a row -- an episode end, a row without a clear accept -- holds the whole wavefront, so
+    // with CUs to spare two wavefronts of two rollouts are faster than one of four.  An empty row is a row that has stopped.
+    const uint32_t rid = wave * 4u + rw;  // (the row's LDS region)
+    const int64_t r = rw < rows_used ? ((int64_t)blockIdx.x * n_chain + wave) * rows_used + rw : (int64_t)ro.R;
     const uint32_t dma_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seg_a + seg_bytes + wave * ROWS_DMA_BYTES));  // this pair's DMA slots
     const uint32_t rbase = seg_a + seg_bytes + rows_dma_total(n_chain) + rid * region_bytes;
     auto dma_slot = [&](uint32_t slot) __attribute__((always_inline)) -> uint32_t { return LV32(dma_a + slot * 256u + lane * 4u); };

@@ -156,7 +156,7 @@ def test_reset_sampler_orders_equal_the_oracle_shuffles(N, nS, p_t0, skew, gpu):
             assert np.array_equal(init_perm[k, :table.N0], O.permutation(seed, table.N0)), (seed, "init")
 
 
-@pytest.mark.parametrize("variant", ["rows_single", "win", "auto", "waves1", "waves2", "waves3"])
+@pytest.mark.parametrize("variant", ["rows_single", "win", "auto", "waves1", "waves2", "waves3", "rpw1", "rpw2"])
 def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
     """The fast path of eval_mc has three bit-identical forms: csrc/scan_rows.hpp with a helper wavefront per chain wavefront
     (four rollouts per wavefront, candidate streams: the default wherever it applies, so the whole in-process suite runs on
@@ -167,7 +167,8 @@ def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
     suite otherwise overrides, tests/conftest.py): the parity, config and edge files once more, whatever kernel each table gets -- and
     whatever launch shape: the row-packed kernel runs with one to four chain wavefronts per workgroup (a launch of few rollouts is spread
     over the CUs, offsim_eval_mc_streams); the suite pins four, "auto" leaves the choice to the launcher, "wavesN" force the other shapes
-    (partly filled workgroups included: 8 rollouts on a workgroup of 12)."""
+    (partly filled workgroups included: 8 rollouts on a workgroup of 12), "rpwN" the number of rollouts a chain wavefront carries (one or
+    two of its four rows instead of all: what a launch of at most two rollouts per CU gets)."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
@@ -179,11 +180,13 @@ def test_every_scan_variant_passes_the_parity_suite(variant, gpu):
         env.pop("OFFSIM_ROWS_WAVES", None)
     elif variant.startswith("waves"):
         env["OFFSIM_ROWS_WAVES"] = variant[5:]
+    elif variant.startswith("rpw"):  # rollouts per chain wavefront (a sparse launch leaves rows of a wavefront empty on purpose)
+        env["OFFSIM_ROWS_PER_WAVE"] = variant[3:]
     else:
         env["OFFSIM_ROWS_HELPER"] = "0"
-    files = ["test_gpu_parity.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant == "waves1" else []) if variant.startswith("waves") else \
+    files = ["test_gpu_parity.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant == "waves1" else []) if variant.startswith(("waves", "rpw")) else \
         ["test_gpu_parity.py", "test_gpu_configs.py", "test_gpu_edges.py"] + (["test_gpu_round2.py"] if variant == "rows_single" else [])
-    skip = "not every_scan_variant and not headline_table_size and not two_ranks" + (" and not headline_job" if variant.startswith("waves") else "")
+    skip = "not every_scan_variant and not headline_table_size and not two_ranks" + (" and not headline_job" if variant.startswith(("waves", "rpw")) else "")
     r = subprocess.run([sys.executable, "-m", "pytest"] + [os.path.join(here, f) for f in files] +
                        ["-m", "gpu", "-x", "-q", "-k", skip],
                        env=env, capture_output=True, text=True, timeout=1800)
