@@ -259,6 +259,8 @@ __global__ void __launch_bounds__(256)
                 const uint64_t o = pcg_output(st);
                 st = pcg_apply(j128, st);
                 const uint32_t idx = (blk * 128u + 2u * (uint32_t)lane) & (SHUF_RG - 1u);
+                // (one aligned 64-bit store; two 32-bit stores time the same here, 0.486 against 0.484 s per reset: the 256 cycles
+                // tools/micro/issue.hip reports for ds_write_b64 are those of a MISALIGNED access, its addresses are lane * 4)
                 *(lds_vu64 *)(ring + idx) = o;  // low half first
                 blk += 2u;
                 done_blocks++;
@@ -364,10 +366,14 @@ __global__ void __launch_bounds__(256)
                     r1 = ring[(c + (uint32_t)lane) & (SHUF_RG - 1u)];
                     r2 = ring[(c + 64u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 }
+#ifdef SHUF_CPUB_EVERY_PAIR
+                sh_st(ctrl + SH_CPUB, c);
+#else
                 if (c - c_pub >= 256u) {  // the draw ring is 2048 deep: G does not need every step
                     c_pub = c;
                     sh_st(ctrl + SH_CPUB, c);
                 }
+#endif
             }
             if (CUT) sh_st(ctrl + SH_CSTOP, (c_start & ~1u) + c);  // (the cut is a mask boundary: i == STOP - 1 here; draws from the stream's start)
             sh_st(ctrl + SH_DONE, 1u);
@@ -449,7 +455,13 @@ __global__ void __launch_bounds__(256)
                     piecewise(64u, i_first, il, v, b, tg, confl, F);
                     SPX1();  // A: groups with a conflict
                 }
-                if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);  // (behind the stores) positions above i_top are final
+                // (behind the stores) positions above i_top are final.  Every group, keyed or not: one store costs less than the test and the
+                // branch that published every fourth group only (reset 0.495 -> 0.484 s, tools/ab_reset.sh; SHUF_ATOP_EVERY_FOURTH: the old form)
+#ifdef SHUF_ATOP_EVERY_FOURTH
+                if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);
+#else
+                sh_st(ctrl + SH_ATOP, i_top);
+#endif
             }
             if (i_top > lo) {  // the last, partial group
                 const uint32_t cnt = i_top - lo;
