@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256)
                         r1 = ring[(c + (uint32_t)lane) & (SHC_RG - 1u)];
                         r2 = ring[(c + 64u + (uint32_t)lane) & (SHC_RG - 1u)];
                     }
-                    if (c - c_pub >= 256u) {
+                    if (c - c_pub >= 256u) {  // (a store every iteration instead: no difference here, 0.445 s either way)
                         c_pub = c;
                         sh_st(ctrl + SH_CPUB, c);
                     }

@@ -269,10 +269,11 @@ __global__ void __launch_bounds__(256)
         } else if (wave == 1) {
             // ---------------- C: the j sequence, 2 x 64 draws per iteration.  The second batch starts from i2 = i - accepts
             // of the first, so the wavefront has two independent instruction streams.
-            uint32_t i = n - 1u, c = c_start & 1u, avail = 0, fill = 0, tail = 0, c_pub = 0;  // (an odd count: the high half of a 64-bit output is next)
+            uint32_t i = n - 1u, c = c_start & 1u, avail = 0, fill = 0, tail = 0;  // (an odd count: the high half of a 64-bit output is next)
             uint32_t mask = 0xffffffffu >> __builtin_clz(i);
             int lowpow = (int)((mask >> 1) + 1u);  // steps below this index use the next smaller mask
             auto wait_draws = [&](uint32_t upto) {
+                if (__builtin_expect(upto <= avail, 1)) return;  // (marked for the block layout of C's loop, like the room check below: 0.472 -> 0.470 s)
                 const bool waited = upto > avail;
                 if (waited) SPW0();
                 uint32_t polls = 0;
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256)
                 if (waited) SPW1();
             };
             auto wait_room = [&](uint32_t upto) {  // the j ring may hold entries [tail, tail + SQ)
+                if (__builtin_expect(upto - tail <= SHUF_SQ, 1)) return;
                 const bool waited = upto - tail > SHUF_SQ;
                 if (waited) SPW0();
                 uint32_t polls = 0;
@@ -366,14 +368,7 @@ __global__ void __launch_bounds__(256)
                     r1 = ring[(c + (uint32_t)lane) & (SHUF_RG - 1u)];
                     r2 = ring[(c + 64u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 }
-#ifdef SHUF_CPUB_EVERY_PAIR
-                sh_st(ctrl + SH_CPUB, c);
-#else
-                if (c - c_pub >= 256u) {  // the draw ring is 2048 deep: G does not need every step
-                    c_pub = c;
-                    sh_st(ctrl + SH_CPUB, c);
-                }
-#endif
+                sh_st(ctrl + SH_CPUB, c);  // (every iteration: the store costs less than the test and the branch that published every 256 draws -- reset 0.485 -> 0.480 s)
             }
             if (CUT) sh_st(ctrl + SH_CSTOP, (c_start & ~1u) + c);  // (the cut is a mask boundary: i == STOP - 1 here; draws from the stream's start)
             sh_st(ctrl + SH_DONE, 1u);
@@ -422,8 +417,13 @@ __global__ void __launch_bounds__(256)
 #ifdef SHUF_FAULT_INJECT  // (test build: this role never starts, so the others run into their bounds -- and so does this wait)
             for (uint32_t polls = 0;; __builtin_amdgcn_s_sleep(1)) shuf_bound(ctrl, polls);
 #endif
-            while (i_top >= 64u + lo) {
-                if (fill - done < 64u) {
+            // The loop is written for its block layout (round 4): what a group costs beyond its LDS round trips is scalar control flow, and the
+            // straightforward `while` form of this loop came out with four TAKEN branches on its common path.  Cold exits are marked, the group
+            // with a conflict is an early `continue`, the loop is rotated: two taken branches per group (reset 0.479 -> 0.472 s; a hand-written
+            // form with one was not faster -- this wavefront re-reads the fill counter every other group and would leave the block as often; the
+            // piecewise path as an out-of-line function: 0.515 s).
+            if (i_top >= 64u + lo) for (;;) {
+                if (__builtin_expect(fill - done < 64u, 0)) {
                     SPW0();
                     uint32_t polls = 0;
                     while (fill - done < 64u) {
@@ -447,21 +447,20 @@ __global__ void __launch_bounds__(256)
                 xwr(v, (uint32_t)lane);  // tag: lanes with the same partner see one winner
                 const uint32_t tg = xrd(v);
                 const uint64_t F = __ballot(tg != (uint32_t)lane);  // lanes that lost a tag
-                if (__builtin_expect((confl | F) == 0ull, 1)) {
-                    xwr(il, b);
-                    xwr(v, a);
-                } else {
+                if (__builtin_expect((confl | F) != 0ull, 0)) {
                     SPW0();
                     piecewise(64u, i_first, il, v, b, tg, confl, F);
                     SPX1();  // A: groups with a conflict
+                    sh_st(ctrl + SH_ATOP, i_top);
+                    if (i_top < 64u + lo) break;
+                    continue;
                 }
+                xwr(il, b);
+                xwr(v, a);
                 // (behind the stores) positions above i_top are final.  Every group, keyed or not: one store costs less than the test and the
-                // branch that published every fourth group only (reset 0.495 -> 0.484 s, tools/ab_reset.sh; SHUF_ATOP_EVERY_FOURTH: the old form)
-#ifdef SHUF_ATOP_EVERY_FOURTH
-                if (keyed && (i_top & 255u) >= 192u) sh_st(ctrl + SH_ATOP, i_top);
-#else
+                // branch that published every fourth group only (reset 0.495 -> 0.484 s, tools/ab_reset.sh)
                 sh_st(ctrl + SH_ATOP, i_top);
-#endif
+                if (__builtin_expect(i_top < 64u + lo, 0)) break;
             }
             if (i_top > lo) {  // the last, partial group
                 const uint32_t cnt = i_top - lo;
