@@ -246,3 +246,53 @@ def test_five_byte_streams_hold_the_same_orders_and_give_the_same_rollouts(gpu, 
         e2["z"] = np.repeat(np.array([0, n_states - 1]), lens).astype(e2["z"].dtype)
         t2 = TransitionTable(e2["z"], e2["actions"], e2["rewards"], e2["z_next"], e2["terminals"], e2["action_distributions"], e2["steps"] == 0, device=gpu)
         assert stream_format(t2) == L.STREAMS_B, (lens, n_states)
+
+
+_SHAPE_JOB = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from rl_offline_simulation_amd import _lib, synth
+from rl_offline_simulation_amd.table import TransitionTable
+from rl_offline_simulation_amd.evaluators import BatchedPSRS
+_lib.load()
+N, nS, nA = 2_000_000, 162, 2
+e = synth.synth_iid(N, nS, nA, seed=21)
+table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+pi = table.policy_slots(synth.dirichlet_policy(nS, nA))
+out = {}
+for R in (1, 3, 250, 600, 1100, 2100):
+    env = BatchedPSRS(table, R)
+    env.reset_sampler(list(range(7, 7 + R)), policy=pi)
+    o = env.eval_mc(pi, 0.99)
+    torch.cuda.synchronize()
+    assert env.scan_variant() == "k_eval_mc_rows"
+    _lib.check_async_faults()
+    for k in ("sum_g", "n_ep", "steps", "cand", "n_len", "status"):
+        out[f"{R}_{k}"] = o[k].cpu().numpy()
+    out[f"{R}_cursor"] = env.state.cursor.cpu().numpy()
+    out[f"{R}_rng"] = env.state.rng.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.timeout(900)
+def test_spread_launches_of_the_row_packed_scan_give_the_packed_launch_results(gpu, tmp_path):
+    """The launcher deals a launch of few rollouts out over the CUs (fewer chain wavefronts per workgroup, and below four rollouts per CU
+    two or one rollouts to a chain wavefront, rows left empty: offsim_eval_mc_streams).  2 M transitions x 1, 3, 250, 600, 1100 and 2100
+    rollouts -- one rollout per wavefront, two, two pairs of two, two and three pairs of four on a 256-CU device -- under the launcher's
+    own choice, against the same jobs packed sixteen rollouts to a CU (four chain wavefronts of four: OFFSIM_ROWS_WAVES=4, every launch
+    before this change): every per-rollout output, the cursors and the stream states, bit for bit.  (The shape is read once per process:
+    two child processes.)"""
+    script = tmp_path / "job.py"
+    script.write_text(_SHAPE_JOB)
+    res = {}
+    for name, extra in (("auto", {}), ("packed", {"OFFSIM_ROWS_WAVES": "4", "OFFSIM_ROWS_PER_WAVE": "4"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("OFFSIM_ROWS_WAVES", "OFFSIM_ROWS_PER_WAVE")}
+        env.update(extra, OFFSIM_SCAN_ROWS="1")
+        r = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / (name + ".npz"))], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[name] = np.load(tmp_path / (name + ".npz"))
+    assert sorted(res["auto"].files) == sorted(res["packed"].files)
+    for k in res["auto"].files:
+        assert np.array_equal(res["auto"][k], res["packed"][k]), k
+    assert int(res["auto"]["2100_steps"].sum()) > 2100 * 500_000  # (whole rollouts: ~1 M steps each)
