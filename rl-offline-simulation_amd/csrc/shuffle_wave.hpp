@@ -323,22 +323,30 @@ __global__ void __launch_bounds__(256)
                 uint32_t i2 = i - n1;
                 uint64_t bal2 = __ballot((int)v2 <= (int)i2);
                 int rk1 = sh_rank(bal1), rk2 = sh_rank(bal2);  // accepts in front of the lane: its draw serves step i - rk
-                if (__builtin_expect((bal1 & __ballot((int)v1 > (int)i - rk1)) != 0ull, 0)) {
-                    settle(bal1, rk1, v1, i);
-                    n1 = (uint32_t)__popcll(bal1);
-                    i2 = i - n1;
-                    bal2 = __ballot((int)v2 <= (int)i2);
-                    rk2 = sh_rank(bal2);
+                // one test for both batches (93 % of the pairs settle nothing; a test and a branch per batch: reset 0.471 against 0.468 s): the
+                // second batch's optimistic ranks are only right if the first one's hold, so whenever either fails the pair is settled in order
+                const uint64_t f1 = bal1 & __ballot((int)v1 > (int)i - rk1), f2 = bal2 & __ballot((int)v2 > (int)i2 - rk2);
+                if (__builtin_expect((f1 | f2) != 0ull, 0)) {
+                    if (f1) {
+                        settle(bal1, rk1, v1, i);
+                        n1 = (uint32_t)__popcll(bal1);
+                        i2 = i - n1;
+                        bal2 = __ballot((int)v2 <= (int)i2);
+                        rk2 = sh_rank(bal2);
+                    }
+                    if ((bal2 & __ballot((int)v2 > (int)i2 - rk2)) != 0ull) settle(bal2, rk2, v2, i2);
                 }
-                if (__builtin_expect((bal2 & __ballot((int)v2 > (int)i2 - rk2)) != 0ull, 0)) settle(bal2, rk2, v2, i2);
                 const uint32_t n2 = (uint32_t)__popcll(bal2);
                 const int i_new = (int)i2 - (int)n2;
                 if (__builtin_expect(i_new >= lowpow, 1)) {
                     // after settling the accepted lanes are exactly those with v <= i - rk: append them in order; the
                     // others store into the trash words behind the ring
                     wait_room(fill + n1 + n2);
-                    const uint32_t a1 = (int)v1 <= (int)i - rk1 ? ((fill + (uint32_t)rk1) & (SHUF_SQ - 1u)) : SHUF_SQ + (uint32_t)lane;
-                    const uint32_t a2 = (int)v2 <= (int)i2 - rk2 ? ((fill + n1 + (uint32_t)rk2) & (SHUF_SQ - 1u)) : SHUF_SQ + (uint32_t)lane;
+                    // (the settled ballots ARE the accepted lanes: one v_cndmask under the mask instead of the accept test once more per lane --
+                    // 0.466 -> 0.4625 s)
+                    uint32_t a1, a2;
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a1) : "v"(SHUF_SQ + (uint32_t)lane), "v"((fill + (uint32_t)rk1) & (SHUF_SQ - 1u)), "s"(bal1));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a2) : "v"(SHUF_SQ + (uint32_t)lane), "v"((fill + n1 + (uint32_t)rk2) & (SHUF_SQ - 1u)), "s"(bal2));
                     jq[a1] = v1;
                     jq[a2] = v2;
                     fill += n1 + n2;
