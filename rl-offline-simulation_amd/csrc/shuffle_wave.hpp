@@ -430,7 +430,14 @@ __global__ void __launch_bounds__(256)
             // with a conflict is an early `continue`, the loop is rotated: two taken branches per group (reset 0.479 -> 0.472 s; a hand-written
             // form with one was not faster -- this wavefront re-reads the fill counter every other group and would leave the block as often; the
             // piecewise path as an out-of-line function: 0.515 s).
-            if (i_top >= 64u + lo) for (;;) {
+            // The loop is written for what its instructions cost the wavefront (round 4): what a group costs beyond its LDS round trips is
+            // scalar control flow and 16-cycle stores, and the straightforward `while` form came out with four TAKEN branches on its common
+            // path.  Cold exits are marked, the group with a conflict returns early, and the loop runs SHUF_A_GROUPS groups per trip, of which
+            // only the last publishes the ring tail and the final-position word (C sizes its appends by the one, the G wavefronts write the
+            // finished order out by the other: both may lag a few groups, and the wavefront publishes before it ever waits at the loop's
+            // end) -- no test, no branch: reset 0.479 -> 0.472 s for the layout, 0.4645 -> 0.4515 s for two groups per trip.  (A hand-written
+            // form with one taken branch per group was not faster; the piecewise path as an out-of-line function: 0.515 s.)
+            auto group = [&](const bool publish) __attribute__((always_inline)) {
                 if (__builtin_expect(fill - done < 64u, 0)) {
                     SPW0();
                     uint32_t polls = 0;
@@ -445,31 +452,46 @@ __global__ void __launch_bounds__(256)
                 }
                 const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
                 done += 64u;
-                sh_st(ctrl + SH_TAIL, done);  // issued after the read: the entries may be overwritten
+                if (publish) sh_st(ctrl + SH_TAIL, done);
                 const uint32_t i_first = i_top;
                 const uint32_t il = i_first - (uint32_t)lane;
                 i_top -= 64u;
-                // a partner inside the group's own later steps: cut in front of the lane that owns that step
                 const uint64_t confl = __ballot(v < il) & __ballot(v > i_top);
                 const uint32_t a = xrd(il), b = xrd(v);
-                xwr(v, (uint32_t)lane);  // tag: lanes with the same partner see one winner
+                xwr(v, (uint32_t)lane);
                 const uint32_t tg = xrd(v);
-                const uint64_t F = __ballot(tg != (uint32_t)lane);  // lanes that lost a tag
+                const uint64_t F = __ballot(tg != (uint32_t)lane);
                 if (__builtin_expect((confl | F) != 0ull, 0)) {
                     SPW0();
                     piecewise(64u, i_first, il, v, b, tg, confl, F);
-                    SPX1();  // A: groups with a conflict
+                    SPX1();
                     sh_st(ctrl + SH_ATOP, i_top);
-                    if (i_top < 64u + lo) break;
-                    continue;
+                    return;
                 }
                 xwr(il, b);
                 xwr(v, a);
-                // (behind the stores) positions above i_top are final.  Every group, keyed or not: one store costs less than the test and the
-                // branch that published every fourth group only (reset 0.495 -> 0.484 s, tools/ab_reset.sh)
-                sh_st(ctrl + SH_ATOP, i_top);
+                if (publish) sh_st(ctrl + SH_ATOP, i_top);
+            };
+#ifndef SHUF_A_GROUPS
+#define SHUF_A_GROUPS 2
+#endif
+            // (written out, not as an inner loop: with `for (g ...) { group(false); if (...) goto out; }` the compiler's layout gave the gain away)
+            if (i_top >= 64u + lo) for (;;) {
+#if SHUF_A_GROUPS >= 4
+                group(false);
+                if (__builtin_expect(i_top < 64u + lo, 0)) break;
+                group(false);
+                if (__builtin_expect(i_top < 64u + lo, 0)) break;
+#endif
+#if SHUF_A_GROUPS >= 2
+                group(false);
+                if (__builtin_expect(i_top < 64u + lo, 0)) break;
+#endif
+                group(true);
                 if (__builtin_expect(i_top < 64u + lo, 0)) break;
             }
+            sh_st(ctrl + SH_TAIL, done);
+            sh_st(ctrl + SH_ATOP, i_top);
             if (i_top > lo) {  // the last, partial group
                 const uint32_t cnt = i_top - lo;
                 uint32_t polls = 0;
