@@ -23,6 +23,7 @@
 // Segments that do not fit (the init queue of a big log, states with > 65536 rows) use the same roles with the
 // segment left in global memory (32-bit entries, in place).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -312,11 +313,19 @@ __global__ void __launch_bounds__(256)
                 }
             };
             wait_draws(c + 128u);
-            uint32_t r1 = ring[c + (uint32_t)lane], r2 = ring[c + 64u + (uint32_t)lane];
-            while (i >= stop_i) {
+            uint32_t ra = ring[c + (uint32_t)lane], rb = ring[c + 64u + (uint32_t)lane], rc = 0, rd = 0;
+#ifndef SHUF_C_PAIRS
+#define SHUF_C_PAIRS 2
+#endif
+            // One iteration: the pair of batches in (ra, rb) -- SEL: in (rc, rd) -- and the next pair prefetched into the other two, which is
+            // where the draws of the NEXT iteration are when this one is over, on the boundary path too.  The loop below alternates, so that
+            // no pair is copied, and only every second iteration publishes the draw counter (no test).  (SHUF_C_PAIRS 1: one per trip.)
+            auto iter = [&](auto SEL, const bool publish) __attribute__((always_inline)) {
+                constexpr bool S = decltype(SEL)::value;
+                const uint32_t r1 = S ? rc : ra, r2 = S ? rd : rb;
                 wait_draws(c + 256u);  // this pair and the prefetch of the next
-                const uint32_t p1 = ring[(c + 128u + (uint32_t)lane) & (SHUF_RG - 1u)];
-                const uint32_t p2 = ring[(c + 192u + (uint32_t)lane) & (SHUF_RG - 1u)];
+                uint32_t p1 = ring[(c + 128u + (uint32_t)lane) & (SHUF_RG - 1u)];
+                uint32_t p2 = ring[(c + 192u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 const uint32_t v1 = r1 & mask, v2 = r2 & mask;
                 uint64_t bal1 = __ballot(v1 <= i);  // optimistic: accepted if no earlier lane of the batch had been accepted
                 uint32_t n1 = (uint32_t)__popcll(bal1);
@@ -353,8 +362,6 @@ __global__ void __launch_bounds__(256)
                     sh_st(ctrl + SH_FILL, fill);
                     i = (uint32_t)i_new;
                     c += 128u;
-                    r1 = p1;
-                    r2 = p2;
                 } else {
                     // a mask boundary (or the end of the chain) inside the pair: batch 1 only, and only the draws -- accepted
                     // or not -- of steps at or above the boundary
@@ -373,11 +380,33 @@ __global__ void __launch_bounds__(256)
                         lowpow = (int)((mask >> 1) + 1u);
                     }
                     wait_draws(c + 128u);
-                    r1 = ring[(c + (uint32_t)lane) & (SHUF_RG - 1u)];
-                    r2 = ring[(c + 64u + (uint32_t)lane) & (SHUF_RG - 1u)];
+                    p1 = ring[(c + (uint32_t)lane) & (SHUF_RG - 1u)];
+                    p2 = ring[(c + 64u + (uint32_t)lane) & (SHUF_RG - 1u)];
                 }
-                sh_st(ctrl + SH_CPUB, c);  // (every iteration: the store costs less than the test and the branch that published every 256 draws -- reset 0.485 -> 0.480 s)
+                if (S) {
+                    ra = p1;
+                    rb = p2;
+                } else {
+                    rc = p1;
+                    rd = p2;
+                }
+                // (a store costs less than the test and the branch that published every 256 draws -- reset 0.485 -> 0.480 s)
+                if (publish) sh_st(ctrl + SH_CPUB, c);
+            };
+#if SHUF_C_PAIRS == 1
+            while (i >= stop_i) {
+                iter(std::false_type{}, true);
+                ra = rc;
+                rb = rd;
             }
+#else
+            while (i >= stop_i) {
+                iter(std::false_type{}, false);
+                if (__builtin_expect(i < stop_i, 0)) break;
+                iter(std::true_type{}, true);
+            }
+            sh_st(ctrl + SH_CPUB, c);
+#endif
             if (CUT) sh_st(ctrl + SH_CSTOP, (c_start & ~1u) + c);  // (the cut is a mask boundary: i == STOP - 1 here; draws from the stream's start)
             sh_st(ctrl + SH_DONE, 1u);
         } else {
