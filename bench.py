@@ -350,12 +350,12 @@ def run(a):
         # Rollouts resident at once: every rollout keeps its queue orders (candidate streams: 4 + 2 bytes per queue position; as
         # permutations 4), its init order, cursors and stream state in HBM.  All of them when they fit -- the chains of a tile run
         # concurrently, tiles run one after the other -- otherwise as many as the free memory of this rank holds.
-        from rl_offline_simulation_amd.evaluators.psrs import rollout_resident_bytes
-        per_rollout = rollout_resident_bytes(table, keyed=a.shuffle == "per_rollout")
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        # (room is left for the chunked shuffle's workspace -- chains of more than 65536 rows --, at most a tenth of what is free)
-        ws_b = min(int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), free_b // 10)
-        fit = int((free_b - (2 << 30) - ws_b) // max(per_rollout, 1)) if a.shuffle == "per_rollout" else n_loc
+        # (room is left for the chunked shuffle's workspace -- chains of more than 65536 rows --, at most a tenth of what is free: the
+        # same rule as the library's own driver, evaluators/psrs.py: resident_rollouts)
+        from rl_offline_simulation_amd.evaluators.psrs import resident_rollouts
+        fit, per_rollout, free_b, total_b = resident_rollouts(table, keyed=a.shuffle == "per_rollout")
+        if a.shuffle != "per_rollout":
+            fit = n_loc
         tile = max(1, min(a.tile if a.tile > 0 else n_loc, n_loc, max(fit, 1)))
         # tiles of ONE size (the last one is filled up with repeats of its last seed, whose results are dropped): a second batch size
         # would be a second set of resident buffers

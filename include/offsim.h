@@ -199,8 +199,10 @@ int offsim_step_server_start(const offsim_table *t, offsim_rollouts *ro, offsim_
 /* The host side of ONE request, in C (no device call: stores to the mailbox, then a spin on seq_out): p_new = n_actions probabilities
  * (f64 / f32 by prob_mode; NULL for RESET), out3 = {row, status, popped}.  Returns OFFSIM_OK, or OFFSIM_SERVER_GONE (> 0) when the
  * server ended by itself before it saw the request -- the request stays posted: synchronise the server's stream, start it again (it
- * serves the posted request) and wait for seq_out == seq_in -- or OFFSIM_EHIP after max_spins polls (0: no bound). */
+ * serves the posted request) and wait for seq_out == seq_in -- or OFFSIM_EHIP after max_spins polls (0: no bound) or, whatever
+ * max_spins says, after OFFSIM_SERVER_ANSWER_SECONDS of wall-clock time (a dead server is reported in seconds, not minutes). */
 #define OFFSIM_SERVER_GONE 1
+#define OFFSIM_SERVER_ANSWER_SECONDS 10.0
 int offsim_step_server_call(offsim_step_mailbox *mailbox, const void *p_new, int32_t n_actions, int32_t prob_mode, uint32_t cmd,
                             int32_t reject_mode, uint64_t max_spins, int32_t *out3);
 
@@ -354,6 +356,13 @@ int offsim_async_faults(void);
  * accepted candidates that way).  *mismatches (device, int64) receives the number of lane operations that returned anything
  * else over ~6e7 randomised ones: 0 on gfx950.  Asynchronous on `stream` like every other entry point. */
 int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
+/* The same property as a runtime guard: 1 when the current device has it, 0 when not (or when OFFSIM_FORCE_LDS_ORDER_MISMATCH=1 is in
+ * the environment: tests), negative OFFSIM_E* when the test could not run.  The first call on a device runs a short self-test (~1e6
+ * lane operations on a stream of its own, synchronised: < 1 ms) and caches the verdict.  offsim_eval_mc_streams and the chunked shuffle
+ * (offsim_shuffle_queues[_keys]_ws with a workspace, format C) call it themselves and return OFFSIM_EUNSUPPORTED on 0 -- never wrong
+ * numbers; callers that want to route around it (to offsim_eval_mc_keys on permutations and a reset without workspace, as the Python
+ * host mirror does) ask first. */
+int offsim_lds_order_ok(void);
 
 /* ---- headline scan on per-rollout candidate streams ------------------------------------------------------------
  * For a fixed tabular policy the scan needs, per candidate, only a 32-bit digest of its compiled key (the top bits of the

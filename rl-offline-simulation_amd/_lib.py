@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OFFSIM_LIB") or os.path.join(_HERE, "csrc", "liboffsim_hip.so")
 
 OK = 0
+EINVAL, EHIP, EUNSUPPORTED = -1, -2, -3
 F32, F64, F16 = 0, 1, 2
 REJECT_DEFAULT, REJECT_NEVER = 0, 1
 STREAM_PCG64, STREAM_PHILOX = 0, 1
@@ -62,6 +63,7 @@ MAILBOX_MAX_ACTIONS = 24
 SERVER_CMD_STEP, SERVER_CMD_POP_ONE, SERVER_CMD_EXIT, SERVER_CMD_RESET = 1, 2, 3, 4
 SERVER_STARTING, SERVER_RUNNING, SERVER_EXITED = 1, 2, 3
 SERVER_GONE = 1  # offsim_step_server_call: the server ended before it saw the request
+SERVER_ANSWER_SECONDS = 10.0  # include/offsim.h: OFFSIM_SERVER_ANSWER_SECONDS
 
 
 class StepMailbox(C.Structure):
@@ -108,6 +110,7 @@ SIGNATURES = {
     "offsim_eval_mc_keys": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, C.c_double, _vp, _i64, _i64,
                                       C.POINTER(EvalMCOut), _vp]),
     "offsim_selftest_lds_atomic_order": (C.c_int, [_vp, _vp]),
+    "offsim_lds_order_ok": (C.c_int, []),
     "offsim_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
     "offsim_host_free": (C.c_int, [_vp]),
     "offsim_step_server_start": (C.c_int, [C.POINTER(Table), C.POINTER(Rollouts), _vp, _i32, C.c_uint32, _vp]),
@@ -156,6 +159,31 @@ def check_async_faults():
     if v:
         what = [n for b, n in ((FAULT_SHUFFLE, "sampler reset (shuffle ring protocol)"), (FAULT_SCAN, "scan (chain / helper hand-off)")) if v & b]
         raise OffsimError("a kernel gave up a bounded wait instead of hanging: " + ", ".join(what) + "; the results of that call are invalid")
+
+
+_LDS_ORDER = {}
+
+
+def lds_order_ok(device=None):
+    """include/offsim.h: offsim_lds_order_ok for `device` (default: the current one) -- whether the LDS of this part serves the
+    same-address lanes of one ds_add_rtn_u32 / ds_wrxchg_rtn_b32 in lane order, which the row-packed scan and the chunked shuffle rely
+    on.  One short self-test per device and process, cached (here and in the library); a device without the property gets one warning
+    and the host mirror routes it to the window kernel on permutations and the in-place shuffle (same results, slower)."""
+    import torch
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _LDS_ORDER:
+        with torch.cuda.device(idx):
+            v = load().offsim_lds_order_ok()
+        if v < 0:
+            check(v)
+        _LDS_ORDER[idx] = bool(v)
+        if not v:
+            import warnings
+            warnings.warn(f"offsim: cuda:{idx} does not apply same-address LDS lanes in lane order (offsim_lds_order_ok = 0): the row-packed "
+                          "scan and the chunked shuffle are off for this device -- window kernel on permutations, in-place shuffle",
+                          RuntimeWarning, stacklevel=2)
+    return _LDS_ORDER[idx]
 
 
 def require_device():

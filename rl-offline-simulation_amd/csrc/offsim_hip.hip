@@ -16,12 +16,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "offsim.h"
 #include "discount.hpp"
 #include "pcg64_dev.hpp"
 #include <rocrand/rocrand_kernel.h>  // device API of Philox4x32-10 (the OFFSIM_STREAM_PHILOX provider)
 
+extern "C" int offsim_lds_order_ok(void);
 #include "shuffle_wave.hpp"
 #include "shuffle_chunk.hpp"
 
@@ -338,6 +340,7 @@ extern "C" int offsim_async_faults(void) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OFFSIM_EHIP, "async_faults: no device%s");
     if (!slot[dev] && hipMalloc((void **)&slot[dev], sizeof(int32_t)) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: allocation failed%s");
     hipLaunchKernelGGL(k_fault_exchange, dim3(1), dim3(1), 0, (hipStream_t)0, slot[dev]);
+    if (hipGetLastError() != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: launch failed%s");
     int32_t v = 0;
     if (hipMemcpy(&v, slot[dev], sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return fail(OFFSIM_EHIP, "async_faults: read failed%s");
     return v;
@@ -421,6 +424,9 @@ static ShcPlan shc_plan(const offsim_table *t, void *workspace, int64_t workspac
 static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *seeds, int32_t n_perm, const uint32_t *dig32, uint32_t *dig_out,
                       void *loc_out, uint32_t *init_perm_out, uint32_t *perm_out, void *workspace, hipStream_t st, uint32_t loc_bits = 16u,
                       uint32_t chains_above = SHUF_CAP16) {
+    // the chunked kernel applies a group of messages with one ds_wrxchg_rtn_b32 per lane and relies on the LDS serving same-address
+    // lanes in lane order: asked once per device (offsim_lds_order_ok)
+    { const int okv = offsim_lds_order_ok(); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "chunked shuffle: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): lend no workspace -- the in-place shuffle does not need it%s"); }
     uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of long chains, [64 ..] their indices, longest first
     hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), chains_above,
                        hdr + 64, hdr + 1, hdr);
@@ -1285,12 +1291,21 @@ extern "C" int offsim_step_server_call(offsim_step_mailbox *mb, const void *p_ne
     const uint32_t seq = m->seq_in + 1u;
     __atomic_store_n(&mb->seq_in2, seq, __ATOMIC_RELEASE);  // behind the payload
     __atomic_store_n(&mb->seq_in, seq, __ATOMIC_RELEASE);   // ... and last
+    // the wait is bounded by polls (max_spins) AND by wall-clock time: OFFSIM_SERVER_ANSWER_SECONDS, looked at every 65536 polls
     uint64_t spins = 0;
+    struct timespec t_start = {0, 0};
     while (__atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 1023u) == 0) {
             if (m->state == OFFSIM_SERVER_EXITED && __atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) return OFFSIM_SERVER_GONE;
             if (max_spins && spins > max_spins) return fail(OFFSIM_EHIP, "step_server_call: the resident step server does not answer%s");
+            if ((spins & 65535u) == 0) {
+                struct timespec now;
+                clock_gettime(CLOCK_MONOTONIC, &now);
+                if (t_start.tv_sec == 0 && t_start.tv_nsec == 0) t_start = now;
+                else if ((double)(now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(now.tv_nsec - t_start.tv_nsec) > OFFSIM_SERVER_ANSWER_SECONDS)
+                    return fail(OFFSIM_EHIP, "step_server_call: the resident step server did not answer in time%s");
+            }
         }
     }
     out3[0] = m->row;
@@ -1741,6 +1756,9 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (sm->format != OFFSIM_STREAMS_A && !sm->loc) return fail(OFFSIM_EINVAL, "eval_mc_streams: formats B and C need the loc stream%s");
     if (sm->format == OFFSIM_STREAMS_C && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: format C holds 255 states%s");
     if (ro->R == 0) return OFFSIM_OK;
+    // the tick takes its queue positions with one ds_add_rtn_u32 per rollout, lane = step, and relies on the LDS serving same-address
+    // lanes in ascending lane order: checked once per device, refused (not silently wrong) where the property is absent
+    { const int okv = offsim_lds_order_ok(); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): use offsim_eval_mc_keys on permutations%s"); }
     hipStream_t st = (hipStream_t)stream;
     const bool trace = out->trace_row || out->trace_pop;
     // four rollouts per wavefront; as many wavefronts per workgroup (<= 4) as the CU's 160 KiB of LDS hold regions for
@@ -1873,6 +1891,42 @@ extern "C" int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *strea
     for (uint32_t n : n_addr) hipLaunchKernelGGL(k_selftest_lds_order, dim3(256), dim3(64), 0, st, 12345u + n, 500, n, (unsigned long long *)mismatches);
     LAUNCH_CHECK();
     return OFFSIM_OK;
+}
+
+// The same self-test as a RUNTIME GUARD (include/offsim.h): run once per device, short (3 launches of 64 wavefronts x 100 trials x the two
+// instructions, ~1.2e6 lane operations), the verdict cached.  offsim_eval_mc_streams and the chunked shuffle ask it before their first
+// launch on a device and refuse (OFFSIM_EUNSUPPORTED) when the LDS of this part does not serve same-address lanes in lane order, instead
+// of returning wrong numbers; the host mirror routes such a device to the window kernel and the in-place shuffle.
+// OFFSIM_FORCE_LDS_ORDER_MISMATCH=1 makes the verdict "absent" (tests).
+extern "C" int offsim_lds_order_ok(void) {
+    static int verdict[64];
+    static bool init = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> hold(mu);
+    if (!init) {
+        for (int &v : verdict) v = -1;
+        init = true;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OFFSIM_EHIP, "lds_order_ok: no device%s");
+    if (verdict[dev] >= 0) return verdict[dev];
+    const char *force = getenv("OFFSIM_FORCE_LDS_ORDER_MISMATCH");
+    if (force && atoi(force) == 1) return verdict[dev] = 0;
+    unsigned long long *bad = nullptr, host = 0;
+    hipStream_t st = nullptr;
+    if (hipMalloc((void **)&bad, sizeof(*bad)) != hipSuccess) return fail(OFFSIM_EHIP, "lds_order_ok: allocation failed%s");
+    // (its own stream: the caller's stream may be capturing, and nothing of the caller's is waited for)
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMemsetAsync(bad, 0, sizeof(*bad), st) == hipSuccess;
+    if (ok) {
+        const uint32_t n_addr[] = {1u, 5u, 162u};
+        for (uint32_t n : n_addr) hipLaunchKernelGGL(k_selftest_lds_order, dim3(64), dim3(64), 0, st, 777u + n, 100, n, bad);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&host, bad, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(bad);
+    if (!ok) return fail(OFFSIM_EHIP, "lds_order_ok: the self-test did not run%s");
+    return verdict[dev] = host == 0 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ through the C ABI of include/offsim.h; the host only moves arguments and payload
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -173,13 +174,16 @@ class BatchedPSRS:
         t = self.table
         if max(t.max_seg, t.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
             return None
+        if not L.lds_order_ok(t.device):  # (the chunked kernel's one-exchange-per-lane apply needs the property: in-place shuffle)
+            return None
         lib = L.load()
         want = torch.cuda.get_device_properties(t.device).multi_processor_count * 4
         n_orders = self.R if n_orders is None else n_orders
         want = min(want, max(1, n_orders * (t.n_slots + 1)))
         # (no more workgroups than keeps each busy with about four chains of the longest kind: a small job does not wait for gigabytes
-        # of pools to be allocated)
-        want = min(want, max(8, n_orders * getattr(t, "long_rows", t.N) // (4 * max(t.max_seg, t.N0, 1))))
+        # of pools to be allocated).  Format C sends EVERY chain of the table through the chunked kernel, not only the long ones.
+        long_rows = (t.N + t.N0) if stream_format(t) == L.STREAMS_C else getattr(t, "long_rows", t.N)
+        want = min(want, max(8, n_orders * long_rows // (4 * max(t.max_seg, t.N0, 1))))
         if getattr(self, "_ws", None) is None or getattr(self, "_ws_wg", 0) < want:
             one = int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 1))
             head = 2 * one - int(lib.offsim_shuffle_workspace_bytes(C.byref(t.c), 2))  # header bytes
@@ -223,6 +227,7 @@ class BatchedPSRS:
         mode = os.environ.get("OFFSIM_SCAN_ROWS", "auto")
         ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
               and mode != "0")
+        ok = ok and L.lds_order_ok(t.device)  # (runtime guard of the tick's lane-ordered LDS atomic; never forced past)
         if not ok or mode == "1":
             return ok
         return ROWS_TICK_STEPS * (t.max_seg / max(t.N, 1)) / max(self._acceptance(policy), 1e-9) < ROWS_MAX_WINDOW_LOAD
@@ -242,8 +247,17 @@ class BatchedPSRS:
         read in that layout whatever the environment says later)."""
         f = self.__dict__.get("_fmt")
         if f is None:
-            f = self._fmt = stream_format(self.table)
+            f = stream_format(self.table)
+            # format C is written by the chunked shuffle only (offsim_shuffle_queues_keys_ws refuses it without a workspace that holds
+            # at least one workgroup's pools, and with an init queue beyond 2^23 rows): decided once the workspace is known, BEFORE the
+            # loc stream is allocated in either width -- under memory pressure the table takes format B and the in-place shuffle
+            if f == L.STREAMS_C and (self.table.N0 > (1 << 23) or not self._workspace_holds_a_workgroup(self._shuffle_workspace())):
+                f = L.STREAMS_B
+            self._fmt = f
         return f
+
+    def _workspace_holds_a_workgroup(self, ws):
+        return ws is not None and ws.numel() >= int(L.load().offsim_shuffle_workspace_bytes(C.byref(self.table.c), 1)) > 0
 
     def _loc_bits(self):
         """Bits of the local row the loc stream holds (the others travel inside the digest: formats B, C)."""
@@ -400,7 +414,10 @@ class BatchedPSRS:
         served by a RESIDENT wavefront (offsim_step_server_start: no kernel launch, no stream synchronise per call -- ~27 us before)
         through a mailbox in host-coherent pinned memory; the server is started on first use, ends by itself when idle, and is stopped
         before anything else touches this environment's state (`_quiesce`).  OFFSIM_STEP_SERVER=0, more than 24 actions, or R != 1: one
-        launch per call, p_new and the results in pinned mapped memory.  Returns host ints (row, status, popped)."""
+        launch per call, p_new and the results in pinned mapped memory.  Returns host ints (row, status, popped).
+        PITFALL: while the server is up (until ~20-40 ms after the last step) any DEVICE-WIDE synchronisation in the caller's own code
+        between two steps -- torch.cuda.synchronize(), empty_cache / hipFree, hipHostFree -- waits for that idle timeout; a loop that
+        must synchronise the device every step sets OFFSIM_STEP_SERVER=0 (one launch per call, ~27 us) or synchronises its own stream."""
         t = self.table
         p_new = np.asarray(p_new)
         mode = _prob_mode(t, p_new.dtype)
@@ -489,11 +506,14 @@ class BatchedPSRS:
         self._server_start(mode)
         mb.seq_in2 = seq
         mb.seq_in = seq
-        spins = 0
-        while mb.seq_out != seq:
+        spins, t_end = 0, None
+        while mb.seq_out != seq:  # (bounded by wall-clock time, like the C side: OFFSIM_SERVER_ANSWER_SECONDS)
             spins += 1
-            if spins > 200_000_000:
-                raise L.OffsimError("the resident step server does not answer")
+            if (spins & 0xFFF) == 0:
+                now = time.monotonic()
+                t_end = now + L.SERVER_ANSWER_SECONDS if t_end is None else t_end
+                if now > t_end:
+                    raise L.OffsimError("the resident step server does not answer")
         row = mb.row
         self.last_row = row
         return row, mb.status, mb.popped
@@ -666,6 +686,20 @@ def rollout_resident_bytes(table, keyed=True):
     return int(table.N) * per_pos + int(table.N0) * 4 + int(table.n_slots) * 4 + 64
 
 
+def resident_rollouts(table, keyed=True, free_bytes=None):
+    """How many rollouts' queue orders the free HBM of the table's device holds at once (shared by bench.py and evalmc_rollouts):
+    rollout_resident_bytes each, after 2 GiB for everything else of the job (policy keys, outputs, rebuilt permutations) and the
+    chunked shuffle's workspace -- pools for up to 1024 persistent workgroups, at most a tenth of what is free -- which
+    `_shuffle_workspace` allocates AFTER the stream buffers and which a table with chains above 65536 rows (or in stream format C,
+    where a missing workspace would cost the format) must still find room for.  Returns (rollouts, bytes per rollout, free, total)."""
+    free_b, total_b = torch.cuda.mem_get_info(table.device)
+    if free_bytes is not None:
+        free_b = int(free_bytes)
+    per = max(rollout_resident_bytes(table, keyed=keyed), 1)
+    ws_b = min(int(L.load().offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), free_b // 10)
+    return int(max(0, free_b - (2 << 30) - ws_b) // per), per, int(free_b), int(total_b)
+
+
 def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, tile=None,
                     reject_mode=L.REJECT_DEFAULT, n_episodes=None):
     """evalMC_psrs for many sampler seeds.  Rollouts are processed in tiles of `tile` seeds so that the per-rollout queue orders
@@ -674,9 +708,7 @@ def evalmc_rollouts(table, seeds, pi, gamma, shuffle=SHUFFLE_PER_ROLLOUT, shuffl
     seeds = np.asarray(seeds, dtype=np.uint64)
     R = len(seeds)
     if tile is None:
-        free_b, _ = torch.cuda.mem_get_info(table.device)
-        per = rollout_resident_bytes(table, keyed=True)
-        tile = R if shuffle != SHUFFLE_PER_ROLLOUT else int(max(1, min(R, (free_b - (2 << 30)) // per)))
+        tile = R if shuffle != SHUFFLE_PER_ROLLOUT else int(max(1, min(R, resident_rollouts(table, keyed=True)[0])))
     pi_slots = table.policy_slots(pi)
     outs = {k: [] for k in ("sum_g", "n_ep", "steps", "cand", "status")}
     env = None

@@ -397,6 +397,23 @@ assert env._ws is not None and v & L.FAULT_SHUFFLE and dt < 10.0
     torch.cuda.synchronize()
     assert a._ws.numel() > (1 << 20) and b._ws.numel() == 8192 and L.load().offsim_async_faults() == 0  # a: chunked kernel, b: in place
     assert torch.equal(a._dig_buf, b._dig_buf) and torch.equal(a._loc_buf, b._loc_buf) and torch.equal(a._init_perm_buf, b._init_perm_buf)
+    # (3) a table that would take stream format C (one state of 100 k rows: 65536 < max_seg <= 2^17), which only the chunked shuffle can
+    # write: with a workspace that holds no workgroup the format is decided as B BEFORE the loc stream is allocated and the reset falls
+    # back to the in-place shuffle instead of raising -- same queue orders, same evaluation
+    e = synth.synth_iid(100000, 1, 2, seed=3)
+    t = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi = t.policy_slots(synth.dirichlet_policy(1, 2))
+    a, b = BatchedPSRS(t, 3), BatchedPSRS(t, 3)
+    b._ws = torch.empty(8192, dtype=torch.uint8, device=gpu)
+    b._ws_wg = 1 << 30
+    a.reset_sampler([7, 8, 9], policy=pi)
+    b.reset_sampler([7, 8, 9], policy=pi)
+    torch.cuda.synchronize()
+    assert a._stream_format() == L.STREAMS_C and a._loc_buf.dtype == torch.uint8 and b._stream_format() == L.STREAMS_B and b._loc_buf.dtype == torch.int16
+    assert L.load().offsim_async_faults() == 0 and torch.equal(a.perm, b.perm) and torch.equal(a._init_perm_buf, b._init_perm_buf)
+    oa, ob = a.eval_mc(pi, 0.99), b.eval_mc(pi, 0.99)
+    torch.cuda.synchronize()
+    assert all(torch.equal(oa[k], ob[k]) for k in ("sum_g", "n_ep", "steps", "cand"))
 
 
 def test_scan_kernel_is_chosen_by_the_table(gpu):
