@@ -504,11 +504,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             // candidates up to the end of the 64-byte sector the head lies in: the window's last top-up came out of that sector, so it
             // is still in L2 / the Infinity Cache (a read of 16 would nearly always reach into the next one: an HBM round trip for
             // candidates the step rarely gets to); the batches behind an all-rejected one are whole sectors
-#ifndef ROWS_DIRECT_WHOLE
             const uint32_t in_sector = 16u - ((uint32_t)((uintptr_t)(dbase + beg + cz) >> 2) & 15u);
-#else
-            const uint32_t in_sector = 16u;
-#endif
             const uint32_t nv = rem < in_sector ? rem : in_sector;
             const bool valid = li < nv;
             const uint32_t dg = valid ? dbase[beg + cz + li] : 0u;
@@ -786,10 +782,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LV32(sync_a + SY_GEN) = gen;  // the first 240 draws are in the ring
         uint32_t fin = 0;
-#ifdef ROWS_DIAG_LAG
-        double lag_sum = 0.0, lag_n = 0.0, lag_over = 0.0, lag_d1 = 0.0, lag_d2 = 0.0, lag_d3 = 0.0;
-        uint32_t lag_max = 0;
-#endif
 #ifdef OFFSIM_ROWS_PROF
         pf_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -811,12 +803,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!ok) break;  // (the chain reports OFFSIM_ST_PROTOCOL when it is the one that gave up; here nothing more can be summed)
-#ifdef ROWS_HELPER_PRIO_LOW
-            __builtin_amdgcn_s_setprio(ROWS_HELPER_PRIO);
-#endif
-#ifdef ROWS_DIAG_LAG
-            lag_d1 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
-#endif
             PF_PH(8);
             // The request areas are free once the previous round's request loads have landed: they were that round's FIRST loads,
             // so at most the ones issued behind them -- the reward pipeline's: reward (one or two dwords), local row, discount
@@ -831,9 +817,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             }
             // The chain has read the RQ slots of the previous round (before it published this tick): mark them "not landed".
             // The helper never waits for the digests it requests; the chain lands what has arrived (it has, a tick later).
-#ifdef ROWS_DIAG_LAG
-            lag_d2 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
-#endif
             const RowsRq rq = rows_rq(ROWS_LAND_LAG == 2 && (k & 1u));  // this round's set of request areas (the chain landed it before it published the tick)
             {
                 // (first of all the set's descriptors go: the chain's dry-row path may look into the request areas at any time, and takes
@@ -851,9 +834,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             fin = LV32(sync_a + SY_FIN);
             cp = LV32(sync_a + SY_C);
             LV32(sync_a + SY_HTICK) = k + 1u;  // (behind the reads of the buffer: the chain may reuse it)
-#ifdef ROWS_DIAG_LAG
-            lag_d3 += (double)((uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u));
-#endif
             {   // the window top-ups this tick's steps call for, first of all (the chain lands them at the end of its next tick:
                 // what has not arrived by then is lost)
                 uint32_t q_s = 0, q_p = 0, q_n = 0;
@@ -862,18 +842,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 LV32(dma_a + rq.s + lane * 4u) = q_s;
             }
             LV32(sync_a + SY_REQ) = k + 1u;
-#ifdef ROWS_HELPER_PRIO_LOW  /* (A/B builds: issue priority only for the request round; the reward pipeline, the draws and the polling below it) */
-            __builtin_amdgcn_s_setprio(ROWS_HELPER_PRIO_LOW);
-#endif
-#ifdef ROWS_DIAG_LAG
-            {
-                const uint32_t dl = (uint32_t)__builtin_amdgcn_s_memtime() - LV32(sync_a + 60u);
-                lag_sum += dl;
-                lag_n += 1.0;
-                lag_over += dl > 2500u ? 1.0 : 0.0;
-                lag_max = dl > lag_max ? dl : lag_max;
-            }
-#endif
             const uint32_t pos_i = positions(n, le);
             PF_PH(9);
             // the slots the reward pipeline reads were loaded by the previous round: everything but this round's request loads
@@ -901,19 +869,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             out.sum_g[r] = sum_g;
             out.n_ep[r] = ep_acc;
             out.n_len[r] = n_len;
-#ifdef ROWS_DIAG_LAG
-            if (out.dbg && out.ep_g && out.ep_cap >= 4) {
-                out.ep_g[r * out.ep_cap + 0] = lag_sum;
-                out.ep_g[r * out.ep_cap + 1] = lag_n;
-                out.ep_g[r * out.ep_cap + 2] = lag_over;
-                out.ep_g[r * out.ep_cap + 3] = (double)lag_max;
-                if (out.ep_cap >= 8) {
-                    out.ep_g[r * out.ep_cap + 4] = lag_d1;
-                    out.ep_g[r * out.ep_cap + 5] = lag_d2;
-                    out.ep_g[r * out.ep_cap + 6] = lag_d3;
-                }
-            }
-#endif
 #ifdef OFFSIM_ROWS_PROF
             if (out.dbg && out.ep_g && out.ep_cap >= 24)
                 for (int k = 0; k < 12; k++) out.ep_g[r * out.ep_cap + 12 + k] = (double)pf_ph[k];
@@ -969,15 +924,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                     }
                 }
             }
-#ifdef ROWS_TICK_CXX
-            uint32_t dsc = LV32(dma_a + rq.d + lane * 4u), dss = LV32(dma_a + rq.s + lane * 4u);
-            in_a = LV128(dma_a + rq.a + lane * 16u), in_b = LV128(dma_a + rq.b + lane * 16u);
-            if (tick_k >= (uint32_t)ROWS_LAND_LAG) {
-                rq_p = dsc & 0xfffffffu;
-                rq_s = dss;
-                rq_n = dsc >> 28;  // (<= 8)
-            }
-#else
             // Landing and hand-off, hand-written (round 4; the compiled form of the same steps -- ROWS_TICK_CXX -- took ~1400 of the
             // tick's 1950 cycles): lane = step of the round that lands.  One batch of reads (descriptor, state, the eight staged
             // digests), a second one (the state's window row and its end), the count of entries the head-aligned row holds, the
@@ -1113,16 +1059,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                 static_assert(SY_TICK == 0 && SY_C == 8 && SY_FIN == 16 && DS_RQD * 256 == 2048 && DS_RQS * 256 == 2304 && DS_RQB * 256 == 1024 && DS_RQA == 0,
                               "the immediates of the hand-written tick");
             }
-#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA loads of the previous tick (issued ~16 iterations ago)
             le = elog;  // (single wavefront: the log never leaves the registers)
             in_a = ROWS_READ_A(), in_b = LV128(dma_a + DS_RQB * 256u + lane * 16u);
         }
         PF_PH(0);
-#ifndef ROWS_TICK_CXX
         if (!HELPER)
-#endif
         {
         // C: land the requested digests.  Entries are appended only at the window's current end: whatever a direct read has
         // covered meanwhile is skipped, whatever does not fit -- or has not arrived -- is requested again later.  The window is
@@ -1166,21 +1109,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             rq_n = 0;
         }
         }
-#ifdef ROWS_TICK_CXX
-        if (HELPER) {
-            // hand the tick's log to the helper: data, then the flag (the LDS runs one wavefront's DS instructions in issue
-            // order) -- BEHIND the landing: the helper aims its next requests at the windows' ends as it finds them, and a
-            // request aimed at an end that is about to move is a request lost
-            LV32(log_a + li4) = elog;  // the tick's sixteen log words, lane = step
-            LV32(sync_a + ((tick_k & 1u) ? SY_N1 : SY_N0)) = n;
-            LV32(sync_a + SY_C) = c;
-            if (dead) LV32(sync_a + SY_FIN) = (uint32_t)status + 1u;
-#ifdef ROWS_DIAG_LAG
-            LV32(sync_a + 60u) = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-            LV32(sync_a + SY_TICK) = tick_k + 1u;
-        }
-#endif
         PF_PH(2);
         if (HELPER) {
             steps += n;
@@ -1330,38 +1258,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         // s[42:43] = lanes.  Nothing of the iteration is committed before the last test has passed; what it leaves for the entry
         // code: the state and the reads of the next look, and in `key` the log word of this step (the first copy after an entry
         // writes "the step before it" from key).
-#ifdef ROWS_DRY_BISECT1  /* (debug build: every dry event leaves for the C++ path after the handler's tests) */
-#define ROWS_DRY_T1 "s_branch 52f\n\t"
-#else
-#define ROWS_DRY_T1
-#endif
-#ifndef ROWS_DRY_IN_SECTOR  /* sixteen candidates whatever the sector (0.903 -> 0.900 s; with non-temporal reward loads it was the other way round) */
+/* sixteen candidates whatever the sector (0.903 -> 0.900 s; with non-temporal reward loads it was the other way round) */
 #define ROWS_DRY_SECTOR "v_mov_b32 v121, 16\n\t"
-#else  /* (A/B build: only the candidates up to the end of the queue head's 64-byte sector) */
-#define ROWS_DRY_SECTOR
-#endif
-// The candidates of a dry row.  Default: straight from the stream.  ROWS_DRY_STAGE (experiment, off): first a look into the request
-// areas -- with two ticks between a request round and its landing a top-up of the very window end is often already on chip (54 % of the
-// dry rows at 10 M x 4096) -- under a seqlock on the descriptor.  It bought nothing measurable (the event is ~1500 cycles either way:
-// five dependent LDS round trips against one memory round trip) and one run in ten of tests/test_gpu_round2.py's 2 M x 256 comparison
-// then differed from the window kernel (a race that was not found): not built.
-#ifdef ROWS_DRY_STAGE
-#define ROWS_DRY_CLAIM_READ "ds_read_u8 v107, v107\n\t"
-#define ROWS_DRY_CANDIDATES ROWS_DRY_CANDIDATES_STAGED
-#else
-#define ROWS_DRY_CLAIM_READ
+// The candidates of a dry row come straight from the stream.  (Round 4 tried a look into the request areas first -- a top-up of the
+// very window end is often already on chip -- under a seqlock on the descriptor: no gain, the event is ~1500 cycles either way, and an
+// unresolved race; the experiment lives in `git log` only.)
 #define ROWS_DRY_CANDIDATES ROWS_DRY_CANDIDATES_STREAM
-#endif
-#ifdef ROWS_DRY_NO_STAGE  /* (debug build: the request areas are never used by the dry-row path) */
-#define ROWS_DRY_NOSTAGE "s_mov_b64 s[36:37], 0\n\t"
-#else
-#define ROWS_DRY_NOSTAGE
-#endif
-#ifdef ROWS_DRY_COUNT_HITS  /* (debug build: rows served from the request areas counted in bits 16.. of the dry counter) */
-#define ROWS_DRY_HITS "v_mov_b32 v99, 0x10000\n\t" "v_cndmask_b32_e64 v99, 0, v99, s[36:37]\n\t" "v_add_u32 %[ndry], %[ndry], v99\n\t"
-#else
-#define ROWS_DRY_HITS
-#endif
 #define ROWS_DRY_CANDIDATES_STREAM                                                                                            \
             "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* grouped position of this lane's candidate */ \
             "v_mov_b32 v125, 0\n\t"                                                                                       \
@@ -1379,103 +1281,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
             "ds_read_b32 v117, v126\n\t"                                 /* draw c + hv + lane */                        \
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-#define ROWS_DRY_CANDIDATES_STAGED                                                                                            \
-            /* ---- Is a top-up of this very window end waiting in the request areas?  (Two ticks pass between a request round and  */ \
-            /* its landing, ROWS_LAND_LAG: most of that time the digests are already on chip.)  The state's claim byte names, per    */ \
-            /* round parity, the lane that made the state's last request; its descriptor says whether it was aimed at the window end */ \
-            /* as it stands (= p), the first word of each group of four whether the group has arrived, and a second look at the      */ \
-            /* descriptor behind the data whether the helper has recycled the set meanwhile (it clears the descriptors first). */ \
-            "v_mbcnt_lo_u32_b32 v108, -1, 0\n\t"                                                                          \
-            "v_mbcnt_hi_u32_b32 v108, -1, v108\n\t"                                                                       \
-            "v_lshlrev_b32 v108, 2, v108\n\t"                                                                             \
-            "v_sub_u32 v108, v108, %[li4]\n\t"                           /* 4 x the row's first lane */                  \
-            "v_add_u32 v108, %[dmaa], v108\n\t"                                                                           \
-            "v_add3_u32 v124, v120, %[e], v118\n\t"                      /* (meanwhile) grouped position of this lane's candidate */ \
-            "v_mov_b32 v125, 0\n\t"                                                                                       \
-            "v_lshl_add_u64 v[124:125], v[124:125], 2, %[dbase]\n\t"                                                      \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "v_and_b32 v106, 15, v107\n\t"                               /* lane of the even rounds' request (set 0) */  \
-            "v_lshrrev_b32 v107, 4, v107\n\t"                            /* ... of the odd rounds' (set 1) */            \
-            "v_lshl_add_u32 v106, v106, 2, v108\n\t"                                                                      \
-            "v_lshl_add_u32 v107, v107, 2, v108\n\t"                                                                      \
-            "ds_read_b32 v100, v106 offset:2048\n\t"                     /* descriptor, state of set 0 */                \
-            "ds_read_b32 v101, v106 offset:2304\n\t"                                                                      \
-            "ds_read_b32 v102, v107 offset:4608\n\t"                     /* ... of set 1 */                              \
-            "ds_read_b32 v103, v107 offset:4864\n\t"                                                                      \
-            "ds_read_b32 v117, v126\n\t"                                 /* (and the draws c + hv + lane: needed last) */ \
-            /* (meanwhile) candidates up to the end of the 64-byte sector the queue's head lies in: what the stream read may take */ \
-            "v_lshrrev_b32 v121, 2, v124\n\t"                                                                             \
-            "v_sub_u32 v121, v121, v118\n\t"                                                                              \
-            "v_and_b32 v121, 15, v121\n\t"                                                                                \
-            "v_sub_u32 v121, 16, v121\n\t"                                                                                \
-            ROWS_DRY_SECTOR                                                                                                \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "v_and_b32 v104, 0xfffffff, v100\n\t"                                                                         \
-            "v_and_b32 v105, 0xfffffff, v102\n\t"                                                                         \
-            "v_cmp_eq_u32_e64 s[36:37], v101, %[zz]\n\t"                                                                  \
-            "v_cmp_eq_u32_e64 s[38:39], v104, %[e]\n\t"                                                                   \
-            "v_cmp_eq_u32_e64 s[40:41], v103, %[zz]\n\t"                                                                  \
-            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                  \
-            "v_cmp_eq_u32_e64 s[38:39], v105, %[e]\n\t"                                                                   \
-            "v_lshrrev_b32 v104, 28, v100\n\t"                           /* entries asked for */                         \
-            "v_lshrrev_b32 v105, 28, v102\n\t"                                                                            \
-            "s_and_b64 s[40:41], s[40:41], s[38:39]\n\t"                                                                  \
-            "v_cmp_ne_u32_e64 s[38:39], 0, v104\n\t"                                                                      \
-            "v_cmp_ne_u32_e32 vcc, 0, v105\n\t"                                                                           \
-            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                 /* set 0 holds a request for this window end */ \
-            "s_and_b64 s[40:41], s[40:41], vcc\n\t"                      /* set 1 does */                                \
-            "s_andn2_b64 s[40:41], s[40:41], s[36:37]\n\t"                                                                \
-            "v_mov_b32 v99, 0xa00\n\t"                                   /* from one set of request areas to the other */ \
-            "v_cndmask_b32_e64 v100, v100, v102, s[40:41]\n\t"           /* the descriptor that counts */                \
-            "v_cndmask_b32_e64 v104, v104, v105, s[40:41]\n\t"                                                            \
-            "v_cndmask_b32_e64 v106, v106, v107, s[40:41]\n\t"                                                            \
-            "v_cndmask_b32_e64 v99, 0, v99, s[40:41]\n\t"                                                                 \
-            "s_or_b64 s[36:37], s[36:37], s[40:41]\n\t"                                                                   \
-            "v_subrev_u32 v105, %[dmaa], v106\n\t"                       /* 4 x the requesting lane */                   \
-            "v_add_u32 v106, v106, v99\n\t"                              /* its descriptor (offset 2048) */              \
-            "v_lshl_add_u32 v105, v105, 2, %[dmaa]\n\t"                  /* its four staged digests */                   \
-            "s_and_b64 s[36:37], s[36:37], s[30:31]\n\t"                 /* (dry rows only) */                           \
-            "v_add_u32 v105, v105, v99\n\t"                                                                               \
-            "s_mov_b64 exec, s[36:37]\n\t"                                                                                \
-            "ds_read_b32 v97, v105\n\t"                                  /* first word of each group: all-ones = not arrived */ \
-            "ds_read_b32 v98, v105 offset:1024\n\t"                                                                       \
-            "v_and_b32 v102, 12, %[li4]\n\t"                                                                              \
-            "v_and_b32 v103, 16, %[li4]\n\t"                                                                              \
-            "v_lshl_add_u32 v102, v103, 6, v102\n\t"                     /* lane 0..3: first group, 4..7: second group */ \
-            "v_add_u32 v105, v105, v102\n\t"                                                                              \
-            "ds_read_b32 v101, v105\n\t"                                 /* this lane's staged candidate (lanes 8..15: not used) */ \
-            "ds_read_b32 v96, v106 offset:2048\n\t"                      /* the descriptor once more, behind the data */ \
-            "s_mov_b64 exec, %[live]\n\t"                                                                                 \
-            "v_cmp_lt_u32_e32 vcc, 4, v104\n\t"                                                                           \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
-            "v_cmp_ne_u32_e64 s[38:39], -1, v97\n\t"                     /* the first group has arrived */               \
-            "v_cmp_ne_u32_e64 s[40:41], -1, v98\n\t"                                                                      \
-            "s_and_b64 s[40:41], s[40:41], vcc\n\t"                      /* the second group was asked for and has arrived */ \
-            "v_cmp_eq_u32_e32 vcc, v96, v100\n\t"                        /* the set has not been recycled */             \
-            "s_and_b64 s[36:37], s[36:37], s[38:39]\n\t"                                                                  \
-            "v_cndmask_b32_e64 v104, 4, 8, s[40:41]\n\t"                 /* staged candidates */                         \
-            "s_and_b64 s[36:37], s[36:37], vcc\n\t"                      /* rows served from the request areas */        \
-            ROWS_DRY_NOSTAGE                                                                                               \
-            /* (a group of four is one load, but its dwords need not appear at once: every staged candidate that counts must be there --   \
-               a lane that still sees the mark sends ALL rows of this event to the stream, which is rare) */                 \
-            "v_cmp_lt_u32_e64 s[38:39], v118, v104\n\t"                  /* lanes with a staged candidate */             \
-            "v_cmp_eq_u32_e32 vcc, -1, v101\n\t"                                                                          \
-            "s_and_b64 s[38:39], s[38:39], s[36:37]\n\t"                                                                  \
-            "s_and_b64 vcc, vcc, s[38:39]\n\t"                                                                            \
-            "s_cselect_b64 s[36:37], 0, s[36:37]\n\t"                                                                     \
-            "s_nop 0\n\t"                                                                                                 \
-            "v_cndmask_b32_e64 v121, v121, v104, s[36:37]\n\t"           /* candidates at hand: the staged ones, or the sector's */ \
-            "v_cmp_lt_u32_e32 vcc, v118, v121\n\t"                                                                        \
-            "s_mov_b64 exec, s[30:31]\n\t"                                                                                \
-            "v_mov_b32 %[zn], -1\n\t"                                  /* (a lane without a candidate accepts nothing) */ \
-            "s_and_b64 exec, exec, vcc\n\t"                                                                               \
-            "s_mov_b64 s[38:39], exec\n\t"                                                                                \
-            "s_andn2_b64 exec, exec, s[36:37]\n\t"                       /* the other rows read the stream */            \
-            "global_load_dword %[w2], v[124:125], off\n\t"                                                                \
-            "s_mov_b64 exec, s[38:39]\n\t"                                                                                \
-            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                           \
-            "v_cndmask_b32_e64 %[w2], %[w2], v101, s[36:37]\n\t"                                                          \
-            ROWS_DRY_HITS
 // (SBIAS / SNBIAS: the format's window bias and its negation; LOGH: formats B and C leave the upper bits of the accepted candidate's local
 // row beside the long-form log word, as the C++ path does)
 #define ROWS_DRY_LOGH                                                                                                        \
@@ -1515,7 +1320,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "v_add_u32 v107, %[zz], %[claimb]\n\t"                                                                        \
             "ds_read_b32 %[e], v123\n\t"                                                                                  \
             "ds_read2_b32 v[120:121], v126 offset1:1\n\t"                                                                 \
-            ROWS_DRY_CLAIM_READ                                                                                            \
             "v_add_u32_dpp %[nrd], %[nrd], %[nrd] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                     \
             "v_lshrrev_b32 v118, 2, %[li4]\n\t"                          /* lane of the row, 0..15 */                    \
             "v_add_u32 v119, 4, %[li4]\n\t"                                                                               \
@@ -1562,7 +1366,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             "s_nop 0\n\t"                                                                                                 \
             "v_cmp_eq_u32_e32 vcc, -1, %[zn]\n\t"                        /* sixteen rejections in a row: the C++ path */ \
             "s_cbranch_vccnz 52f\n\t"                                                                                     \
-            ROWS_DRY_T1                                                                                                    \
             /* ---- every test has passed: commit.  The dry rows first (exec): draw counter, log word, land ---- */       \
             "v_add_u32 %[c4], 0xffffff01, %[c4]\n\t"                                                                      \
             "v_lshl_add_u32 %[c4], %[nrd], 2, %[c4]\n\t"                                                                  \
@@ -1737,24 +1540,12 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                       rows_format(OFFSIM_STREAMS_C).amb == 0xfff40000u && (rows_format(OFFSIM_STREAMS_C).emask | 0x400u) == 0x3c03ff00u, "the literals of the format-C loop");
         static_assert(RO_SYNC - RO_RING == 1280u && SY_TICK == 0 && RO_LOGH - RO_RING == 1408u && rows_format(OFFSIM_STREAMS_B).bias == 0x20000u &&
                       rows_format(OFFSIM_STREAMS_C).bias == 0x80000u, "immediates of the dry-row handler");
-#if defined(ROWS_NO_DRY_ASM) || defined(ROWS_NO_DRY_ASM_BC)
-        if constexpr (fmt_c) {
-            ROWS_FAST_ASM("0x3ffff", "0x4ff", "0xfff40000", "0x3c03ff00", "6", "");
-        } else if constexpr (fmt_b) {
-            ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "6", "");
-        } else {
-#else
         if constexpr (fmt_c) {
             ROWS_FAST_ASM("0x3ffff", "0x4ff", "0xfff40000", "0x3c03ff00", "5", ROWS_DRY_HANDLER("0x80000", "0xfff80000", ROWS_DRY_LOGH));
         } else if constexpr (fmt_b) {
             ROWS_FAST_ASM("0xffff", "0x4ff", "0xfffd0000", "0x3c00ff00", "5", ROWS_DRY_HANDLER("0x20000", "0xfffe0000", ROWS_DRY_LOGH));
         } else {
-#endif
-#if defined(ROWS_NO_DRY_ASM) || (defined(ROWS_DRY_STAGE) && ROWS_LAND_LAG != 2)  // A/B builds: every row without a clear accept takes the C++ path, as in round 3
-            ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "6", "");
-#else
             ROWS_FAST_ASM("0x7ff", "0x7ff", "0xffff7800", "0x3c000400", "5", ROWS_DRY_HANDLER("0x8000", "0xffff8000", ""));
-#endif
         }
 #undef ROWS_FAST_ASM
 #undef ROWS_DRY_HANDLER
@@ -1798,9 +1589,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             exact_step(it, amb);
             PS(8);
         }
-#ifndef ROWS_T_NODRAWCHECK  /* (timing experiment only) */
         if (!dead) need_draws((ROWS_TICK - (it + 1u)) * 8u + 8u, it + 1u);
-#endif
         PS(9);
     };
 
