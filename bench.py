@@ -48,9 +48,11 @@ def parse():
     ap.add_argument("--rollouts", type=int, default=4096, help="sampler seeds (rollouts)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--no-rollout-sharded", action="store_true", help="skip the extra rollout-sharded measurement of a strong multi-GPU run")
-    ap.add_argument("--workload", default="iid", choices=["iid", "cartpole", "grid"],
-                    help="iid = S-iid synthetic log (headline); cartpole = CartPole dynamics + device box encoder (config C2); "
-                         "grid = continuous_grid log + 2-64-25 MLP encoder forward on MFMA, random-init weights (config C3)")
+    ap.add_argument("--workload", default="iid", choices=["iid", "cartpole", "grid", "obs128"],
+                    help="iid = S-iid synthetic log (headline; --transitions 12500000 = one GPU's shard of config C4); cartpole = CartPole "
+                         "dynamics + device box encoder (config C2); grid = continuous_grid log + 2-64-25 MLP encoder forward on MFMA (config C3); "
+                         "obs128 = 128-d fp16 observations -> 128-64-50 encoder forward on MFMA -> fp16 p_log table (config C5; one GPU's share "
+                         "of its 50 M rows is --transitions 6250000)")
     ap.add_argument("--n-states", type=int, default=162)
     ap.add_argument("--n-actions", type=int, default=2)
     ap.add_argument("--shuffle", default="per_rollout", choices=["per_rollout", "shared", "table_order"])
@@ -69,7 +71,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="create the process group and run the all-reduce of the per-seed estimates even with ONE "
                                                               "rank (legal for RCCL): the only way a one-GPU box executes the collective leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configurations (C2 CartPole 1 M x 4096, C3 continuous_grid 10 M x 4096 "
-                                                              "with the MLP encoder) that the default single-GPU headline run appends under \"configs\"")
+                                                              "with the MLP encoder, one GPU's shard of C4 12.5 M x 4096, one GPU's shard of C5 6.25 M x 4096 "
+                                                              "with 128-d fp16 observations) that the default single-GPU headline run appends under \"configs\"")
     ap.add_argument("--print-csrc-digest", action="store_true", help="print the digest of the kernel sources (recorded by tools/profile_bench.sh) and exit")
     return ap.parse_args()
 
@@ -127,7 +130,10 @@ def spawn_ranks(a):
 def oracle_for(e):
     from oracle import oracle as O
     O.lib()
-    return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0)
+    p = e["action_distributions"]
+    if p.dtype == np.float16:  # (C5: the oracle consumes the fp16-rounded values)
+        p = p.astype(np.float64)
+    return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], p, e["steps"] == 0)
 
 
 def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_seed=1234):
@@ -269,11 +275,87 @@ def make_log(a, seed, dev):
         a.encode_s = time.perf_counter() - t_e
         note = f", host-to-z encode {a.encode_s:.2f} s"
         a.n_states, a.n_actions = 25, 5
+    elif a.workload == "obs128":
+        e, note = make_obs128_log(a, N, seed, dev)
     else:
         e = synth.synth_iid(N, a.n_states, a.n_actions, seed=seed)
         a.encode_s = 0.0
     a.generate_s = time.perf_counter() - t_gen - a.encode_s
     return e, note
+
+
+def make_obs128_log(a, N, seed, dev):
+    """Config C5's shape: observations N(0,1)-coded [N,128] fp16, encoder 128-64-50 on the device (HOMEREncoder.encode's
+    forward + arg-max, encoders/homer.py:159-168 of the reference, csrc/encode_mfma.hpp here), logging probabilities kept fp16 in HBM.
+    The S-iid generator makes the log's columns (nS = 50, nA = 4); an observation is the 128-d code of its logged state plus 0.3 x N(0,1)
+    noise, generated and encoded on the device (the observations never exist on the host: 2 x N x 256 B), and z / z_next are what the
+    ENCODER says -- the oracle's parity run consumes the same encoded states and the fp16-rounded probabilities.  No trained checkpoint
+    travels: the weights are built so that hidden unit k answers to code k and latent k to hidden unit k (a trained HOMER encoder
+    populates its latent states; random-init weights collapse onto a few), stated in the line.  Sets a.encode_s (HIP events around the two
+    forwards) and a.encoder (rows, bytes per row, the arg-max against the oracle's MLP on a sample)."""
+    import torch
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.encoders import HOMEREncoder
+    dO, H, nZ, nA = 128, 64, 50, 4
+    e = synth.synth_iid(N, nZ, nA, seed=seed)
+    g = np.random.default_rng(seed + 77)
+    code = g.standard_normal((nZ, dO)).astype(np.float32)
+    W1 = np.zeros((H, dO), np.float32)
+    W1[:nZ] = code / (code * code).sum(1, keepdims=True)
+    W1[nZ:] = g.standard_normal((H - nZ, dO)).astype(np.float32) / np.sqrt(dO) * 0.1
+    b1 = np.zeros(H, np.float32)
+    W2 = np.zeros((nZ, H), np.float32)
+    W2[np.arange(nZ), np.arange(nZ)] = 1.0
+    W2[:, nZ:] = g.standard_normal((nZ, H - nZ)).astype(np.float32) * 0.01
+    b2 = np.zeros(nZ, np.float32)
+    enc = HOMEREncoder(dO, nA, nZ, H, state_dict={"obs_encoder.0.weight": torch.from_numpy(W1), "obs_encoder.0.bias": torch.from_numpy(b1),
+                                                  "obs_encoder.2.weight": torch.from_numpy(W2), "obs_encoder.2.bias": torch.from_numpy(b2)}, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 78)
+    code_d = torch.from_numpy(code).to(dev)
+
+    def observe(z):  # [N,128] fp16 on the device, in blocks (the f32 intermediate of 6.25 M rows would be 3.2 GB)
+        zt = torch.from_numpy(np.ascontiguousarray(z)).to(dev)
+        out = torch.empty((N, dO), dtype=torch.float16, device=dev)
+        for b in range(0, N, 1 << 20):
+            zz = zt[b:b + (1 << 20)]
+            out[b:b + (1 << 20)] = (code_d[zz] + 0.3 * torch.randn((zz.numel(), dO), device=dev, generator=gen)).to(torch.float16)
+        return out
+
+    obs, nobs = observe(e["z"]), observe(e["z_next"])
+    enc.encode_device(obs[:1024])  # (warm-up: module load)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0.record()
+    z_d, zn_d = enc.encode_device(obs), enc.encode_device(nobs)
+    t1.record()
+    torch.cuda.synchronize()
+    a.encode_s = t0.elapsed_time(t1) * 1e-3
+    z_true = e["z"]
+    e["z"], e["z_next"] = z_d.cpu().numpy().astype(np.int64), zn_d.cpu().numpy().astype(np.int64)
+    e["action_distributions"] = e["action_distributions"].astype(np.float16)
+    # the arg-max against the oracle's MLP (oracle/psrs_oracle.c: mlp_encode, f32 like the reference's torch forward) on a sample of
+    # rows whose top-2 logits are 1e-4 apart or more
+    from oracle import oracle as O
+    k = min(N, 4096)
+    zo, lo = O.mlp_encode(obs[:k].cpu().numpy().astype(np.float32), W1, b1, W2, b2)
+    top2 = np.sort(lo, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+    enc_ok = bool(np.array_equal(e["z"][:k][clear], zo[clear]))
+    bytes_row = dO * 2 + 4
+    a.encoder = {"shape": "128-64-50, fp16 observations, f32 weights (bf16 x 3 exact split on MFMA)", "rows": 2 * N, "encode_s": a.encode_s,
+                 "rows_per_s": 2 * N / a.encode_s, "bytes_per_row": bytes_row,
+                 "roofline": {"bound": "hbm", "achieved": 2 * N * bytes_row / a.encode_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                              "frac": 2 * N * bytes_row / a.encode_s / 8e12},
+                 "argmax_equals_oracle_mlp": enc_ok, "argmax_rows_checked": int(clear.sum()),
+                 "latent_equals_logged_state_frac": float((e["z"] == z_true).mean()),
+                 "weights": "built so that hidden unit k answers to the 128-d code of state k and latent k to hidden unit k (no trained checkpoint travels)"}
+    if not enc_ok:
+        raise SystemExit("bench.py: the device encoder's arg-max differs from the oracle's MLP on rows with a clear arg-max -- no number is reported")
+    a.n_states, a.n_actions = nZ, nA
+    del obs, nobs
+    torch.cuda.empty_cache()
+    return e, f", encoder forward {a.encode_s * 1e3:.1f} ms for 2 x {N} rows"
 
 
 def take_rows(e, mask):
@@ -335,7 +417,7 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full, pi=pi):
+    def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full, pi=pi, diag=False):
         """n_warm + n_timed passes of seeds[seed_lo:seed_hi] over the table of e_rank.  Returns the timing, the per-kernel HIP-event
         times and the per-seed results of the last pass."""
         torch.cuda.synchronize()
@@ -429,11 +511,34 @@ def run(a):
                    rows=table.N, tile=tile, variant=env_for(tile).scan_variant() if a.rng == "pcg64" else "k_eval_mc", seg=(table.min_seg, table.max_seg),
                    resident=int(resident), hbm_free=int(free_b), hbm_total=int(total_b), ingest_s=t_ing, est_local=local.get("est"))
         _lib.check_async_faults()  # (the barrier synchronised: no kernel of these passes gave up a bounded wait)
+        # bytes one pass of the sampler reset writes: every rollout's queue orders (6 / 5 bytes per position as candidate streams, 4 as
+        # permutations) and its init order
+        res["reset_bytes_pass"] = float(n_loc) * (per_rollout - table.n_slots * 4 - 64) if a.shuffle == "per_rollout" else float(per_rollout)
+        res["plog_dtype"] = str(table.p_log.dtype).replace("torch.", "")
+        # Untimed, after the timed region: one more pass of the last tile with the kernel's own clock read-out (eval_mc(dbg=True): shader
+        # cycles and 100 MHz ticks of every chain wavefront, top-up and dry-row counters) -- what explains the roofline fraction of a
+        # kernel that is bound by the latency of its dependent chains, not by HBM.  Row-packed kernel only.
+        res["chain"] = None
+        if diag and res["variant"] == "k_eval_mc_rows" and a.rng == "pcg64" and n_timed > 0:
+            sd = sd_all[-tile:] if n_loc >= tile else np.concatenate([sd_all, np.repeat(sd_all[-1:], tile - n_loc)])
+            env = env_for(len(sd))
+            env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots)
+            o = env.eval_mc(pi_slots, a.gamma, dbg=True)
+            torch.cuda.synchronize()
+            raw = o["dbg"].cpu().numpy()
+            cyc, rt = raw[:, 2].astype(float), raw[:, 3].astype(float)
+            its = float(o["steps"].max().item())
+            res["chain"] = {"cycles_per_iteration": float(cyc.mean() / max(its, 1.0)), "iterations": its, "shader_clock_GHz": float((cyc / np.maximum(rt, 1.0)).mean() * 0.1),
+                            "slowest_chain_ms": float(rt.max() * 1e-5), "mean_chain_ms": float(rt.mean() * 1e-5),
+                            "rows_without_clear_accept_per_rollout": float((raw[:, 0] & 0xffffffff).mean()),
+                            "top_ups_per_rollout": float((raw[:, 0] >> 32).mean()), "top_ups_late_per_rollout": float(((raw[:, 1] >> 16) & 0xffffff).mean()),
+                            "exact_looks_per_rollout": float((raw[:, 1] & 0xffff).mean())}
+            _lib.check_async_faults()
         del envs, table
         torch.cuda.empty_cache()
         return res
 
-    m = measure(e, 0, R, a.warmup, a.steps, False)
+    m = measure(e, 0, R, a.warmup, a.steps, False, diag=True)
     extra = None
     if strong and world > 1 and not a.no_rollout_sharded:
         lo, hi = shard_rollouts(R, rank, world)
@@ -466,10 +571,11 @@ def run(a):
         import copy
         b = copy.copy(a)
         b.workload, b.transitions = workload, transitions
+        b.encoder = None
         e_c, _ = make_log(b, 20221107, dev)
         pi_c = synth.dirichlet_policy(b.n_states, b.n_actions)
         a_sh, a_rng = a.shuffle, a.rng
-        x = measure(e_c, 0, R, 1, 2, False, pi=pi_c)
+        x = measure(e_c, 0, R, 1, 2, False, pi=pi_c, diag=True)
         b_c = x["b_c"] + 4
         alg = x["my_cand"] * b_c + x["my_steps"] * x["b_s"]
         out_c = {"workload": f"{workload}, {transitions} transitions x {R} rollouts, nS={b.n_states}, nA={b.n_actions}", "value": x["steps_pass"] * 2 / x["elapsed"],
@@ -478,7 +584,14 @@ def run(a):
                  "buffer_consumed_frac": x["cand_pass"] / (R * transitions), "segment_rows_min_max": list(x["seg"]),
                  "roofline": {"bound": "hbm", "achieved": alg * 2 / x["t_scan"] / 1e9, "peak": 8000.0, "unit": "GB/s",
                               "frac": alg * 2 / x["t_scan"] / 1e9 / 8000.0, "bytes_per_candidate": b_c, "bytes_per_step": x["b_s"]},
+                 "roofline_reset": {"bound": "hbm", "achieved": x["reset_bytes_pass"] * 2 / x["t_reset"] / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": x["reset_bytes_pass"] * 2 / x["t_reset"] / 8e12, "bytes_written_per_pass": x["reset_bytes_pass"]},
+                 "p_log": x["plog_dtype"], "queue_orders_resident_bytes": x["resident"],
                  "log_generate_s_host": b.generate_s, "encode_s": b.encode_s, "ingest_s": x["ingest_s"]}
+        if x["chain"]:
+            out_c["chain"] = x["chain"]
+        if getattr(b, "encoder", None):
+            out_c["encoder"] = b.encoder
         if not a.no_parity_check:
             ps = [sd for sd in PARITY_SEEDS if sd < R]
             got = {sd: {k: (float(v[sd]) if k == "sum_g" else int(v[sd])) for k, v in x["acc"].items()} for sd in ps}
@@ -492,7 +605,11 @@ def run(a):
 
     configs = None
     if headline and not a.no_configs:
-        configs = {"C2": extra_config("C2", "cartpole", 1_000_000 // test_scale), "C3": extra_config("C3", "grid", 10_000_000 // test_scale)}
+        configs = {"C2": extra_config("C2", "cartpole", 1_000_000 // test_scale), "C3": extra_config("C3", "grid", 10_000_000 // test_scale),
+                   # one GPU's shard of C4 (100 M transitions over 8 GPUs: 12.5 M rows x all 4096 seeds; stream format C, 5 bytes per position)
+                   "C4_shard": extra_config("C4_shard", "iid", 12_500_000 // test_scale),
+                   # one GPU's share of C5 (50 M rows of 128-d fp16 observations over 8 GPUs: 6.25 M rows x 4096 seeds, encoder on MFMA, fp16 p_log)
+                   "C5_shard": extra_config("C5_shard", "obs128", 6_250_000 // test_scale)}
 
     if rank == 0:
         elapsed, t_scan, t_reset, n_scan = m["elapsed"], m["t_scan"], m["t_reset"], m["n_scan"]
@@ -512,6 +629,7 @@ def run(a):
                      f"weak: {world} logs of {a.transitions} transitions, one per GPU, all {R} seeds on each, one RCCL all-reduce of per-seed (sum G, n episodes)")
         wl = (f"CartPole-dynamics log, uniform logger, device box encoder (C2)" if a.workload == "cartpole" else
               f"continuous_grid log, uniform logger, 2-64-25 MLP encoder on MFMA, weights built to map an observation to its cell (C3){enc_note}" if a.workload == "grid" else
+              f"128-d fp16 observations, 128-64-50 MLP encoder on MFMA (weights built to decode the observation's state code), fp16 p_log (C5){enc_note}" if a.workload == "obs128" else
               f"S-iid synthetic log (SURVEY 8d), nS={a.n_states}, nA={a.n_actions}")
         out = {
             "metric": "simulated steps/sec (node), 10M logged transitions x 4096 rollouts",
@@ -521,7 +639,7 @@ def run(a):
             "config": {"workload": f"{wl}, {a.transitions} transitions {'in total' if strong else 'per GPU'} x {R} rollouts, evalMC_psrs to exhaustion, gamma={a.gamma}",
                        "transitions": a.transitions, "transitions_on_rank0": n_rank, "rollouts": R, "shuffle": a.shuffle, "rollout_tile": m["tile"],
                        "queue_orders_resident_bytes_rank0": m["resident"], "hbm_free_bytes_rank0": m["hbm_free"], "hbm_total_bytes_rank0": m["hbm_total"],
-                       "p_log": "f32", "rng": a.rng, "sharding": shard_txt, "segment_rows_min_max": list(m["seg"])},
+                       "p_log": m["plog_dtype"], "rng": a.rng, "sharding": shard_txt, "segment_rows_min_max": list(m["seg"])},
             "candidates_per_s": m["cand_pass"] * a.steps / elapsed, "acceptance": m["steps_pass"] / max(m["cand_pass"], 1.0),
             "buffer_consumed_frac": m["cand_pass"] / (R * a.transitions * (1 if strong else world)),
             "value_estimate_mean": float(np.nanmean(vest)),
@@ -531,8 +649,23 @@ def run(a):
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes_pass / max(n_scan / a.steps, 1),
                          "bytes_per_candidate": b_c, "bytes_per_step": b_s, "launches": n_scan,
-                         "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3, "rank": 0},
+                         "avg_launch_ms": t_scan / max(n_scan, 1) * 1e3, "rank": 0,
+                         "traffic_ratio": (traffic / (alg_bytes_pass / max(n_scan / a.steps, 1))) if traffic else None},
+            # the sampler reset beside it: bytes it writes (queue orders as candidate streams / permutations + init orders) / its time
+            "roofline_reset": {"bound": "hbm", "kernels": "k_shuffle_wave (+ k_shuffle_chunked)", "achieved": m["reset_bytes_pass"] * a.steps / max(t_reset, 1e-12) / 1e9,
+                               "peak": 8000.0, "unit": "GB/s", "frac": m["reset_bytes_pass"] * a.steps / max(t_reset, 1e-12) / 8e12,
+                               "bytes_written_per_pass": m["reset_bytes_pass"],
+                               "bound_measured": "instruction issue of the single classifier / applier wavefront of each Fisher-Yates chain (LDS-resident; the only HBM traffic is the coalesced write-out)"},
         }
+        if m["chain"]:
+            # why `frac` is what it is: the scan is 4096 exact dependent chains, a chain wavefront retires one accepted step of its four
+            # rollouts per iteration, and the kernel lasts (iterations) x (cycles per iteration) / clock -- measured by the kernel's own clock
+            # in one extra untimed pass.  step_floor_cycles: the hand-scheduled step alone beside a busy helper wavefront
+            # (tools/micro/step_loop.hip, profiles/r04_step_loop_microbench.txt); the rest is tick, dry rows, episode ends.
+            out["roofline"].update({"bound_measured": "chain latency / instruction issue of one in-order wavefront per four rollouts",
+                                    "cycles_per_iteration": m["chain"]["cycles_per_iteration"], "step_floor_cycles": 185, "chain": m["chain"]})
+        if getattr(a, "encoder", None):
+            out["encoder"] = a.encoder
         if extra:
             out["rollout_sharded"] = extra
         if coll:

@@ -88,3 +88,31 @@ def test_shard_rollouts_covers_everything():
         spans = [shard_rollouts(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_shards_at_world_3_7_8_with_rollouts_that_do_not_divide():
+    """shard_rollouts / shard_episodes at the world sizes the 8-GPU node runs (and two awkward ones): the rollout slices are disjoint,
+    ordered and cover [0, R) whatever R % world is (ranks past the end get an empty slice), the episode shards are a partition of the
+    ROWS into whole episodes, and a per-rank [R,2] table that is zero outside its slice sums to the full table."""
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.distributed import shard_episodes, shard_rollouts
+    e = synth.synth_iid(20_000, 25, 5, seed=8)
+    ids = e["episode_ids"]
+    for world in (3, 7, 8):
+        for R in (4096, 4099, 13, 5, 1):
+            spans = [shard_rollouts(R, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == R and all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans if hi > lo) <= -(-R // world)
+            full = np.arange(2 * R, dtype=np.float64).reshape(R, 2)
+            acc = np.zeros_like(full)
+            for lo, hi in spans:  # what bench.py's rollout-sharded all-reduce assembles
+                part = np.zeros_like(full)
+                part[lo:hi] = full[lo:hi]
+                acc += part
+            assert np.array_equal(acc, full)
+        masks = [shard_episodes(ids, r, world) for r in range(world)]
+        assert np.array_equal(np.sum(masks, axis=0), np.ones(len(ids), int))  # every row in exactly one shard
+        for m in masks:
+            assert not (set(ids[m]) & set(ids[~m]))  # whole episodes
+        sizes = [int(m.sum()) for m in masks]
+        assert min(sizes) > 0.5 * len(ids) / world  # round-robin by episode id: no starved rank

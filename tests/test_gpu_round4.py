@@ -112,10 +112,21 @@ def test_bench_line_carries_the_extra_configurations(gpu):
     own bench call): OFFSIM_BENCH_CONFIG_SCALE shrinks the two logs."""
     out = _bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env_extra={"OFFSIM_BENCH_TEST_SCALE": "50"}, timeout=900)
     cfg = out["configs"]
-    assert set(cfg) == {"C2", "C3"}
-    for k in ("C2", "C3"):
+    assert set(cfg) == {"C2", "C3", "C4_shard", "C5_shard"}  # (round 5: one GPU's shard of C4 and of C5 are driver-timed lines too)
+    for k in cfg:
         assert cfg[k]["parity_ok"] is True and cfg[k]["value"] > 0 and cfg[k]["scan_s"] > 0 and cfg[k]["kernel"].startswith("k_eval_mc")
+        assert 0 < cfg[k]["roofline"]["frac"] < 1 and 0 < cfg[k]["roofline_reset"]["frac"] < 1
+    c5 = cfg["C5_shard"]
+    assert c5["p_log"] == "float16" and c5["roofline"]["bytes_per_candidate"] == 4 * 2 + 4 + 4
+    enc = c5["encoder"]
+    assert enc["argmax_equals_oracle_mlp"] is True and enc["argmax_rows_checked"] > 1000 and enc["bytes_per_row"] == 260 and 0 < enc["roofline"]["frac"] < 1
+    assert enc["latent_equals_logged_state_frac"] > 0.99
     assert out["parity_check"]["ok"]
+    # the line explains its own fraction: the kernel's clock read-out, the reset's fraction beside the scan's
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["cycles_per_iteration"] > rf["step_floor_cycles"] > 0 and "chain" in rf["bound_measured"]
+    assert rf["chain"]["iterations"] > 0 and 1.0 < rf["chain"]["shader_clock_GHz"] < 3.0
+    assert 0 < out["roofline_reset"]["frac"] < 1 and out["roofline_reset"]["bytes_written_per_pass"] > 0
 
 
 def test_step_server_serves_the_same_steps_as_one_launch_per_call(gpu):

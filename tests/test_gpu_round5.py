@@ -96,3 +96,41 @@ print("ok")
     env = dict(os.environ, OFFSIM_FORCE_LDS_ORDER_MISMATCH="1", OFFSIM_SCAN_ROWS="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(1200)
+def test_bench_plumbing_at_world_size_8_on_one_device(gpu):
+    """What the driver's 8-GPU run executes, with the eight ranks sharing this box's one GPU and gloo carrying the collective:
+    `bench.py --gpus 8` starts its eight ranks itself (children of a process that never touched the GPU), the log is split into eight
+    episode-disjoint shards with all 4096 seeds on each, the extra rollout-sharded measurement gives every rank 512 seeds of the whole
+    log, rank 0 alone prints the line and checks four seeds of ITS shard against the oracle while the others wait in the barrier.
+    No scaling number is expected from this -- the plumbing is: shard arithmetic, tile sizing, the [R,2] all-reduce at world 8."""
+    out = _bench(["--gpus", "8", "--all-ranks-on-device0", "--dist-backend", "gloo", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                 env_extra={"OFFSIM_BENCH_TEST_SCALE": "200"}, timeout=1200)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["test_scale"] == 200
+    c = out["collective"]
+    assert c["world"] == 8 and c["backend"] == "gloo" and c["bytes"] == 4096 * 2 * 8 and c["allreduce_us"] > 0
+    assert out["parity_check"]["ok"] and out["parity_check"]["table_rows"] == out["config"]["transitions_on_rank0"]
+    assert 0 < out["config"]["transitions_on_rank0"] < out["config"]["transitions"] == 50_000
+    rs = out["rollout_sharded"]
+    assert rs["rollouts_per_gpu"] == 512 and rs["transitions_per_gpu"] == 50_000 and rs["value"] > 0
+    # every seed's estimate went through the all-reduce: the mean over seeds of sum(G)/n is finite, and the steps of all eight shards are in
+    assert np.isfinite(out["value_estimate_mean"]) and out["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_obs128_workload_alone(gpu):
+    """`bench.py --workload obs128` (config C5's shape as its own command): device-generated 128-d fp16 observations, the encoder
+    forward on MFMA, an fp16 p_log table, reset + scan with its oracle parity check and the encoder's own roofline object."""
+    out = _bench(["--workload", "obs128", "--transitions", "200000", "--rollouts", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert out["parity_check"]["ok"] and out["config"]["p_log"] == "float16"
+    assert out["roofline"]["bytes_per_candidate"] == 16 and out["encoder"]["argmax_equals_oracle_mlp"] is True
