@@ -69,6 +69,7 @@ def stream_format(table):
 
 ROWS_TICK_STEPS = 16  # steps between two top-up rounds of the row-packed scan (csrc/scan_rows.hpp: ROWS_TICK)
 ROWS_MAX_WINDOW_LOAD = 1.2  # candidates a tick takes out of the busiest 8-entry window, above which the window kernel is the faster scan
+ROWS_MAX_ALL_REJECTED = 0.03  # probability that a full 8-entry window holds no accept, from which the 32-entry window kernel (<= 64 states) is the faster scan
 
 
 def _prob_mode(table, p_dtype):
@@ -230,7 +231,16 @@ class BatchedPSRS:
         ok = ok and L.lds_order_ok(t.device)  # (runtime guard of the tick's lane-ordered LDS atomic; never forced past)
         if not ok or mode == "1":
             return ok
-        return ROWS_TICK_STEPS * (t.max_seg / max(t.N, 1)) / max(self._acceptance(policy), 1e-9) < ROWS_MAX_WINDOW_LOAD
+        # Round 5 (tools/diag_scan.py, profiles/r05_diag_scan_c2_c3_c5.txt): L says nothing about a window that is FULL and still gives no
+        # clear accept -- eight entries are all rejected with probability (1 - acceptance)^8: 0.2 % of the looks at 0.54, 6.5 % at
+        # 0.29 (C5's shard: 50 states, 4 actions, L = 1.1 -- the row-packed kernel ran at 1210 cycles per iteration, 13 % of its
+        # row-steps without a clear accept: 0.878 + 0.433 s per pass against 0.755 + 0.257 s for the window kernel).  Up to 64 states
+        # the window kernel keeps 32 entries per state, where this cannot happen; beyond 64 it has 8 as well and the row-packed
+        # kernel stays ahead at any acceptance (162 states at 0.24: 1.08 against 1.17 s).
+        acc = max(self._acceptance(policy), 1e-9)
+        if t.n_slots <= 64 and (1.0 - min(acc, 1.0)) ** 8 >= ROWS_MAX_ALL_REJECTED:
+            return False
+        return ROWS_TICK_STEPS * (t.max_seg / max(t.N, 1)) / acc < ROWS_MAX_WINDOW_LOAD
 
     def _acceptance(self, policy):
         """Acceptance probability of a candidate under `policy`, averaged over the table's rows: the mean of the compiled thresholds'
