@@ -276,9 +276,15 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     if (n_blocks > 0x7fffffffll) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues: too many chains%s");
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_BIG>), 160 * 1024));
     HIP_TRY(allow_big_lds((k_shuffle_wave<true, SHUF_SQ_SMALL>), 160 * 1024));
+    // the applier's exchange form (one ds_mskor_rtn_b32 per lane instead of the tag round) where the LDS serves same-address lanes in
+    // lane order (offsim_lds_order_ok: once per device); elsewhere the tag form -- same orders
+    static const bool no_xchg = getenv("OFFSIM_SHUFFLE_XCHG") && atoi(getenv("OFFSIM_SHUFFLE_XCHG")) == 0;
+    const int okv = offsim_lds_order_ok();
+    if (okv < 0) return okv;
+    const uint32_t a_xchg = (okv == 1 && !no_xchg) ? 1u : 0u;
     if (!big_segments_elsewhere && (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16)) {  // first: these chains are the long ones (or the chunked kernel has them)
         hipLaunchKernelGGL((k_shuffle_wave<false, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), shuf_fixed_lds_bytes(SHUF_SQ_SMALL), st, t->seg_off,
-                           t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out);
+                           t->n_slots, t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, SHUF_CAP16, 0xffffffffu, dig32, dig_out, loc_out, 0u);
         LAUNCH_CHECK();
     }
     // LDS-resident segments by size class, longest first: the LDS of a launch is sized for its class, so several short
@@ -301,7 +307,7 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     do {                                                                                                                              \
         HIP_TRY(allow_big_lds((k_shuffle_wave<true, SQ, TOP, STOP>), 160 * 1024));                                                     \
         hipLaunchKernelGGL((k_shuffle_wave<true, SQ, TOP, STOP>), dim3((unsigned)n_blocks), dim3(256), (LDSB), st, t->seg_off, t->n_slots, \
-                           t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);                     \
+                           t->N, t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out, a_xchg);             \
         LAUNCH_CHECK();                                                                                                               \
     } while (0)
 #define SHUF_TAILB(TOP) (shuf_fixed_lds_bytes(SHUF_SQ_SMALL) + (size_t)(TOP) * 2 + 16)
@@ -312,13 +318,13 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
 #undef SHUF_TAILB
             if (init_in)  // (an init queue of this size class: its chains are not keyed)
                 hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_BIG>), dim3((unsigned)n_perm), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N,
-                                   t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, nullptr, nullptr);
+                                   t->N0, seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, nullptr, nullptr, a_xchg);
         } else if (k == 0)
             hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_BIG>), dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0,
-                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
+                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out, a_xchg);
         else
             hipLaunchKernelGGL((k_shuffle_wave<true, SHUF_SQ_SMALL>), dim3((unsigned)n_blocks), dim3(256), lds16, st, t->seg_off, t->n_slots, t->N, t->N0,
-                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out);
+                               seeds, n_perm, perm_out, init_perm_out, lo, hi, dig32, dig_out, loc_out, a_xchg);
         LAUNCH_CHECK();
     }
     return OFFSIM_OK;
@@ -1878,6 +1884,30 @@ __global__ void k_selftest_lds_order(uint32_t seed0, int trials, uint32_t n_addr
         }
         __syncthreads();
         if (active && (got != want || cell[a] != last)) nbad++;
+        __syncthreads();
+        // ... and for ds_mskor_rtn_b32 on one HALF of a dword (round 5: the LDS-resident shuffle's applier exchanges a 16-bit entry with
+        // it -- the word's other half, which another lane of the same instruction may be exchanging, must survive): a lane gets back the
+        // half as the previous lane with its (word, half) left it, the last such lane's value stays, the other half is untouched by it
+        for (uint32_t i = lane; i < 256; i += 64) cell[i] = (7000u + i) << 16 | (3000u + i);
+        __syncthreads();
+        const uint32_t half = (hl >> 5) & 1u, sh = half * 16u;
+        if (active) {
+            const uint32_t addr = (uint32_t)(uintptr_t)(offsim::lds_u32 *)&cell[a];
+            asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(addr), "v"(0xffffu << sh), "v"((lane + 1u) << sh) : "memory");
+            got = (got >> sh) & 0xffffu;
+        }
+        want = half ? 7000u + a : 3000u + a;
+        last = want;
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t aj = __shfl(a, j), hj = __shfl(half, j);
+            const bool actj = __shfl((int)active, j);
+            if (actj && aj == a && hj == half) {
+                if (j < lane) want = j + 1u;
+                last = j + 1u;
+            }
+        }
+        __syncthreads();
+        if (active && (got != want || ((cell[a] >> sh) & 0xffffu) != last)) nbad++;
         __syncthreads();
     }
     if (nbad) atomicAdd(bad, nbad);

@@ -101,7 +101,7 @@ template <bool LDS16, uint32_t SHUF_SQ, uint32_t TOP = 0, uint32_t STOP = 1>
 __global__ void __launch_bounds__(256)
     k_shuffle_wave(const uint32_t *__restrict__ seg_off, int32_t n_slots, int64_t N, int64_t N0, const uint64_t *__restrict__ seeds,
                    int32_t n_perm, uint32_t *__restrict__ perm, uint32_t *__restrict__ init_perm, uint32_t n_lo, uint32_t n_hi,
-                   const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out) {
+                   const uint32_t *__restrict__ dig32, uint32_t *__restrict__ dig_out, uint16_t *__restrict__ loc_out, uint32_t a_xchg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     lds_vu32 *ctrl = (lds_vu32 *)lds_raw;
     lds_vu32 *ring = ctrl + 16;
@@ -501,9 +501,69 @@ __global__ void __launch_bounds__(256)
                 xwr(v, a);
                 if (publish) sh_st(ctrl + SH_ATOP, i_top);
             };
+            // Round 5, the exchange form of a group (LDS-resident segments, a_xchg): step l of the group is swap(x[i_l], x[v_l]) with the
+            // i_l distinct and above every partner of a LATER lane, so as long as no partner is a later step's own position (confl, plain
+            // arithmetic -- those groups take the tag round and the pieces as before) the group is: a_l = x[i_l] read up front (it does
+            // not wait for the partners: one LDS round trip together with them), ONE atomic exchange of the 16-bit entry x[v_l] <- a_l per
+            // lane, x[i_l] <- what came back.  Lanes with EQUAL partners need no tags and no pieces: the LDS serves the lanes of one
+            // instruction that hit the same word in ascending lane order (= step order), so a lane gets back exactly what the sequential
+            // chain would find there (the property offsim_lds_order_ok checks on every device before this form is chosen).  The exchange of
+            // a 16-bit half is ds_mskor_rtn_b32 (D = (D & ~mask) | data, returns the old word) on the entry's half of its dword; the other
+            // half, which another lane may be exchanging in the same instruction, is preserved by the masks.  Four DS instructions and
+            // two round trips per group instead of seven and three.
+            typedef __attribute__((address_space(3))) unsigned char lds_b8;
+            const uint32_t x16_a = (uint32_t)(uintptr_t)(lds_b8 *)x16;
+            auto group_x = [&](const bool publish) __attribute__((always_inline)) {
+                if (__builtin_expect(fill - done < 64u, 0)) {
+                    SPW0();
+                    uint32_t polls = 0;
+                    while (fill - done < 64u) {
+                        fill = sh_ld(ctrl + SH_FILL);
+                        if (fill - done < 64u) {
+                            shuf_bound(ctrl, polls);
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    SPW1();
+                }
+                const uint32_t i_first = i_top;
+                const uint32_t il = i_first - (uint32_t)lane;
+                const uint32_t v = jq[(done + (uint32_t)lane) & (SHUF_SQ - 1u)];
+                const uint32_t a = (uint32_t)x16[il];
+                done += 64u;
+                if (publish) sh_st(ctrl + SH_TAIL, done);
+                i_top -= 64u;
+                const uint64_t confl = __ballot(v < il) & __ballot(v > i_top);
+                if (__builtin_expect(confl != 0ull, 0)) {  // a partner is a later step's own position: the tag round and the pieces
+                    SPW0();
+                    const uint32_t b = (uint32_t)x16[v];
+                    x16[v] = (uint16_t)lane;
+                    const uint32_t tg = (uint32_t)x16[v];
+                    piecewise(64u, i_first, il, v, b, tg, confl, __ballot(tg != (uint32_t)lane));
+                    SPX1();
+                    sh_st(ctrl + SH_ATOP, i_top);
+                    return;
+                }
+                const uint32_t sh = (v & 1u) << 4;
+                uint32_t old;
+                asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(old)
+                             : "v"(x16_a + ((v & ~1u) << 1)), "v"(0xffffu << sh), "v"(a << sh)
+                             : "memory");
+                x16[il] = (uint16_t)(old >> sh);
+                if (publish) sh_st(ctrl + SH_ATOP, i_top);
+            };
 #ifndef SHUF_A_GROUPS
 #define SHUF_A_GROUPS 2
 #endif
+            if (LDS16 && a_xchg) {
+                if (i_top >= 64u + lo) for (;;) {
+                    group_x(false);
+                    if (__builtin_expect(i_top < 64u + lo, 0)) break;
+                    group_x(true);
+                    if (__builtin_expect(i_top < 64u + lo, 0)) break;
+                }
+            } else
             // (written out, not as an inner loop: with `for (g ...) { group(false); if (...) goto out; }` the compiler's layout gave the gain away)
             if (i_top >= 64u + lo) for (;;) {
 #if SHUF_A_GROUPS >= 4

@@ -432,7 +432,7 @@ from rl_offline_simulation_amd.table import TransitionTable
 from rl_offline_simulation_amd.evaluators import BatchedPSRS
 assert "OFFSIM_SCAN_ROWS" not in os.environ
 # a hot state; neither; low acceptance alone (round 3's rule took the window kernel here); low acceptance AND rather few states
-# ... and (round 5) 50 equal states at four actions: L = 1.1, but a FULL 8-entry window is all rejected in 6 % of the looks at acceptance 0.29 -- the
+# ... and (round 5) 50 equal states at four actions: L = 1.1, but a FULL 8-entry window is all rejected in 6 %% of the looks at acceptance 0.29 -- the
 # 32-entry window kernel; the same acceptance with 70 states (beyond 64 the window kernel has 8 entries too) stays on the row-packed kernel
 for nS, nA, want in ((10, 2, "k_eval_mc_win"), (120, 2, "k_eval_mc_rows"), (120, 5, "k_eval_mc_rows"), (40, 5, "k_eval_mc_win"), (50, 4, "k_eval_mc_win"),
                      (70, 4, "k_eval_mc_rows")):
