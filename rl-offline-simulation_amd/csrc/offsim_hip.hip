@@ -311,9 +311,14 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
         LAUNCH_CHECK();                                                                                                               \
     } while (0)
 #define SHUF_TAILB(TOP) (shuf_fixed_lds_bytes(SHUF_SQ_SMALL) + (size_t)(TOP) * 2 + 16)
+#ifdef SHUF_PROF  // (tools/prof_shuffle.py: the stamps of the LAST launch survive in the streams -- OFFSIM_SHUFFLE_PROF_LAUNCHES = 1 / 2 stops after the first / second)
+            const int prof_launches = getenv("OFFSIM_SHUFFLE_PROF_LAUNCHES") ? atoi(getenv("OFFSIM_SHUFFLE_PROF_LAUNCHES")) : 3;
+#else
+            const int prof_launches = 3;
+#endif
             SHUF_LAUNCH(SHUF_SQ_BIG, 0, SHUF_CUT_HI, lds16);
-            SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_HI, SHUF_CUT_LO, SHUF_TAILB(SHUF_CUT_HI));
-            SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_LO, 1, SHUF_TAILB(SHUF_CUT_LO));
+            if (prof_launches >= 2) SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_HI, SHUF_CUT_LO, SHUF_TAILB(SHUF_CUT_HI));
+            if (prof_launches >= 3) SHUF_LAUNCH(SHUF_SQ_SMALL, SHUF_CUT_LO, 1, SHUF_TAILB(SHUF_CUT_LO));
 #undef SHUF_LAUNCH
 #undef SHUF_TAILB
             if (init_in)  // (an init queue of this size class: its chains are not keyed)

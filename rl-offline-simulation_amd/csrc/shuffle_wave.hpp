@@ -556,7 +556,135 @@ __global__ void __launch_bounds__(256)
 #ifndef SHUF_A_GROUPS
 #define SHUF_A_GROUPS 2
 #endif
-            if (LDS16 && a_xchg) {
+            // The same groups as one hand-scheduled loop (SHUF_A_ASM, the default): the compiled form above waits for every LDS access
+            // of the volatile segment in turn -- three round trips per group (partners + own entries, the exchange, the store of what came
+            // back before the next group's reads may go).  The LDS executes one wavefront's DS instructions in issue order, so none of
+            // these waits is needed for correctness; here the NEXT group's partners and own entries are requested as soon as this group's
+            // exchange has been issued (its reads come behind the exchange in the LDS queue: a partner of this group that is one of the
+            // next group's own positions is seen), the wavefront waits for the exchange only, stores what came back, and finds the next
+            // group's operands nearly there.  Two copies of the group per trip, the second publishes the ring tail and the final-position
+            // word.  Left with a code: 0 = the chain's full groups are done, 1 = the group at i_top has a partner among its own later
+            // positions (nothing of it applied; v_cur holds its partners), 2 = the next group's partners are not in the ring yet.
+            uint32_t v_cur = 0, a_cur = 0, il_cur = 0;
+            auto run_x = [&]() __attribute__((always_inline)) -> uint32_t {
+                uint32_t code, t_sh, t_ad, t_m, t_d, t_old, t_wa, t_ja;
+                const uint32_t jq_lane = (uint32_t)(uintptr_t)(lds_b8 *)jq + 4u * (uint32_t)lane, ctrl_a = (uint32_t)(uintptr_t)(lds_b8 *)ctrl;
+                il_cur = i_top - (uint32_t)lane;
+#define SHUF_AX_GROUP(G, GW, WAIT, NEXT, PUBLISH)                                                                             \
+                G ":\n\t"                                                                                                    \
+                "s_waitcnt lgkmcnt(" WAIT ")\n\t"                            /* this group's partners and own entries (NOT the stores issued behind them: the LDS answers one wavefront in issue order) */ \
+                GW ":\n\t"                                                                                                   \
+                "s_sub_u32 s21, %[it], 64\n\t"                                                                               \
+                "v_cmp_lt_u32_e32 vcc, %[v], %[il]\n\t"                                                                      \
+                "v_cmp_lt_u32_e64 s[22:23], s21, %[v]\n\t"                                                                   \
+                "v_lshlrev_b32_e32 %[sh], 4, %[v]\n\t"                      /* (v & 1) << 4 in its low five bits */         \
+                "v_lshrrev_b32_e32 %[ad], 1, %[v]\n\t"                                                                       \
+                "s_and_b64 s[22:23], s[22:23], vcc\n\t"                     /* partners among the group's own later positions */ \
+                "s_cbranch_scc1 91f\n\t"                                                                                      \
+                "v_lshl_add_u32 %[ad], %[ad], 2, %[x16a]\n\t"               /* the dword that holds entry v */               \
+                "v_lshlrev_b32_e32 %[m], %[sh], %[ffff]\n\t"                                                                 \
+                "v_lshlrev_b32_e32 %[d], %[sh], %[a]\n\t"                                                                    \
+                "ds_mskor_rtn_b32 %[old], %[ad], %[m], %[d]\n\t"           /* x[v] <- a, lanes with one v in lane order */   \
+                "v_lshl_add_u32 %[wa], %[il], 1, %[x16a]\n\t"                                                                \
+                "s_add_u32 %[done], %[done], 64\n\t"                                                                         \
+                "s_mov_b32 %[it], s21\n\t"                                                                                   \
+                "v_subrev_u32_e32 %[il], 64, %[il]\n\t"                                                                      \
+                "s_cmp_lt_u32 %[it], %[lo64]\n\t"                                                                            \
+                "s_cbranch_scc1 92f\n\t"                                                                                      \
+                "s_sub_u32 s20, %[fill], %[done]\n\t"                                                                        \
+                "s_cmp_lt_u32 s20, 64\n\t"                                                                                   \
+                "s_cbranch_scc1 93f\n\t"                                                                                      \
+                "s_and_b32 s20, %[done], %[sqm]\n\t"                                                                         \
+                "v_lshl_add_u32 %[ja], s20, 2, %[jql]\n\t"                                                                   \
+                "ds_read_b32 %[v], %[ja]\n\t"                                /* the next group's partners ... */             \
+                "v_lshl_add_u32 %[ja], %[il], 1, %[x16a]\n\t"                                                                \
+                "ds_read_u16 %[a], %[ja]\n\t"                                /* ... and own entries, behind the exchange */  \
+                "s_waitcnt lgkmcnt(2)\n\t"                                   /* the exchange */                              \
+                "s_nop 0\n\t"                                                                                                \
+                "v_lshrrev_b32_e32 %[old], %[sh], %[old]\n\t"                                                                \
+                "ds_write_b16 %[wa], %[old]\n\t"                             /* x[i] <- what was at x[v] */                  \
+                PUBLISH                                                                                                      \
+                "s_branch " NEXT "\n\t"
+#define SHUF_AX_PUBLISH                                                                                                       \
+                "v_mov_b32_e32 %[m], %[done]\n\t"                                                                            \
+                "v_mov_b32_e32 %[d], %[it]\n\t"                                                                              \
+                "ds_write_b32 %[ctrl], %[m] offset:16\n\t"                   /* SH_TAIL */                                   \
+                "ds_write_b32 %[ctrl], %[d] offset:24\n\t"                   /* SH_ATOP */
+                asm volatile(
+                    "s_and_b32 s20, %[done], %[sqm]\n\t"
+                    "v_lshl_add_u32 %[ja], s20, 2, %[jql]\n\t"
+                    "ds_read_b32 %[v], %[ja]\n\t"
+                    "v_lshl_add_u32 %[ja], %[il], 1, %[x16a]\n\t"
+                    "ds_read_u16 %[a], %[ja]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_branch 82f\n\t"
+#if SHUF_A_GROUPS >= 4
+                    SHUF_AX_GROUP("80", "82", "3", "84f", "")                /* behind the reads: the entry store and the two words of the last copy */
+                    SHUF_AX_GROUP("84", "85", "1", "86f", "")
+                    SHUF_AX_GROUP("86", "87", "1", "81f", "")
+#else
+                    SHUF_AX_GROUP("80", "82", "3", "81f", "")                /* behind the reads: the entry store and the two words of the copy below */
+#endif
+                    SHUF_AX_GROUP("81", "83", "1", "80b", SHUF_AX_PUBLISH)   /* behind the reads: the entry store of the copy above */
+                    "91:\n\t"                                                /* a conflict: nothing of this group is applied */
+                    "s_mov_b32 %[code], 1\n\t"
+                    "s_branch 99f\n\t"
+                    "92:\n\t"                                                /* the chain's last full group */
+                    "s_mov_b32 %[code], 0\n\t"
+                    "s_branch 94f\n\t"
+                    "93:\n\t"                                                /* the ring does not hold the next group's partners yet */
+                    "s_mov_b32 %[code], 2\n\t"
+                    "94:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_nop 0\n\t"
+                    "v_lshrrev_b32_e32 %[old], %[sh], %[old]\n\t"
+                    "ds_write_b16 %[wa], %[old]\n\t"
+                    "99:\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : [it] "+s"(i_top), [done] "+s"(done), [il] "+v"(il_cur), [v] "+v"(v_cur), [a] "+v"(a_cur), [code] "=&s"(code), [sh] "=&v"(t_sh),
+                      [ad] "=&v"(t_ad), [m] "=&v"(t_m), [d] "=&v"(t_d), [old] "=&v"(t_old), [wa] "=&v"(t_wa), [ja] "=&v"(t_ja)
+                    : [fill] "s"(fill), [lo64] "s"(64u + lo), [sqm] "s"(SHUF_SQ - 1u), [x16a] "v"(x16_a), [jql] "v"(jq_lane), [ffff] "v"(0xffffu),
+                      [ctrl] "v"(ctrl_a)
+                    : "vcc", "scc", "memory", "s20", "s21", "s22", "s23");
+                static_assert(SH_TAIL == 4 && SH_ATOP == 6, "the immediates of the applier's loop");
+#undef SHUF_AX_GROUP
+#undef SHUF_AX_PUBLISH
+                return code;
+            };
+#ifndef SHUF_A_ASM
+#define SHUF_A_ASM 1
+#endif
+            if (LDS16 && a_xchg && SHUF_A_ASM) {
+                while (i_top >= 64u + lo) {
+                    if (__builtin_expect(fill - done < 64u, 0)) {
+                        SPW0();
+                        uint32_t polls = 0;
+                        while (fill - done < 64u) {
+                            fill = sh_ld(ctrl + SH_FILL);
+                            if (fill - done < 64u) {
+                                shuf_bound(ctrl, polls);
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                        }
+                        SPW1();
+                    }
+                    const uint32_t code = run_x();
+                    if (code == 1u) {  // the group at i_top: the tag round and the pieces, as in the compiled form
+                        SPW0();
+                        const uint32_t i_first = i_top, il = i_first - (uint32_t)lane, v = v_cur;
+                        done += 64u;
+                        i_top -= 64u;
+                        const uint64_t confl = __ballot(v < il) & __ballot(v > i_top);
+                        const uint32_t b = (uint32_t)x16[v];
+                        x16[v] = (uint16_t)lane;
+                        const uint32_t tg = (uint32_t)x16[v];
+                        piecewise(64u, i_first, il, v, b, tg, confl, __ballot(tg != (uint32_t)lane));
+                        SPX1();
+                    }
+                    sh_st(ctrl + SH_TAIL, done);
+                    sh_st(ctrl + SH_ATOP, i_top);
+                }
+            } else if (LDS16 && a_xchg) {
                 if (i_top >= 64u + lo) for (;;) {
                     group_x(false);
                     if (__builtin_expect(i_top < 64u + lo, 0)) break;
