@@ -39,8 +39,12 @@ namespace offsim {
 // (tools/time_reset.py ... keyed): uncut 0.645 s; one cut at 4096 / 8192 / 16384 / 32768: 0.575 / 0.548 / 0.540 / 0.568 s;
 // two cuts at 16384 + 4096: 0.528 s, 16384 + 2048: 0.529 s; three cuts at 16384 + 4096 + 1024: 0.535 s, 32768 + 8192 + 2048:
 // 0.536 s, 16384 + 8192 + 2048: 0.538 s, 32768 + 16384 + 4096: 0.552 s
+#ifndef SHUF_CUT_HI
 #define SHUF_CUT_HI 16384u
+#endif
+#ifndef SHUF_CUT_LO
 #define SHUF_CUT_LO 4096u
+#endif
 #define SHUF_SQ_BIG 4096u
 #define SHUF_SQ_SMALL 1024u
 #define SHUF_CAP16 65536u
