@@ -14,7 +14,7 @@ env = BatchedPSRS(table, R)
 for rep in range(2):
     env.reset_sampler(list(range(R)), policy=pi)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record(); o = env.eval_mc(pi, 0.99, dbg=True, ep_cap=8 if os.environ.get("ROWS_DIAG_LAG") else 0); t1.record(); torch.cuda.synchronize()
+    t0.record(); o = env.eval_mc(pi, 0.99, dbg=True); t1.record(); torch.cuda.synchronize()
 raw = o["dbg"].cpu().numpy()
 n_dry, n_req = (raw[:, 0] & 0xffffffff).astype(float), (raw[:, 0] >> 32).astype(float)
 n_tie, n_late, n_miss = (raw[:, 1] & 0xffff).astype(float), ((raw[:, 1] >> 16) & 0xffffff).astype(float), (raw[:, 1] >> 40).astype(float)
@@ -28,9 +28,3 @@ print("by workgroup % 8, per row: top-ups", np.round([n_req.reshape(-1, 16)[b::8
       " window end had moved", np.round([n_miss.reshape(-1, 16)[b::8].mean() for b in range(8)], 0))
 print("by workgroup % 8: dry events per row", np.round([dry[b::8].mean() for b in range(8)], 0), " cycles per iteration", np.round([cyc.reshape(-1, 4)[b::8].mean() / it for b in range(8)], 1))
 print("by workgroup % 8: wall ms", np.round([rt.reshape(-1, 4)[b::8].mean() * 1e-5 for b in range(8)], 1), " clock GHz", np.round([(cyc / rt).reshape(-1, 4)[b::8].mean() * 0.1 for b in range(8)], 3))
-if os.environ.get("ROWS_DIAG_LAG"):  # library built with -DROWS_DIAG_LAG: cycles from the chain's publishing a tick to the helper's having issued its requests
-    g = o["ep_g"].cpu().numpy()[::4].reshape(-1, 4, 8)
-    for par in (0, 1):
-        x = g[par::2].reshape(-1, 8)
-        print(f"workgroups of parity {par}: tick -> requests issued: mean {x[:, 0].sum() / x[:, 1].sum():.0f} cycles, over 2500 in {x[:, 2].sum() / x[:, 1].sum() * 100:.2f} % of the ticks, max {x[:, 3].max():.0f};"
-              f" tick seen at {x[:, 4].sum() / x[:, 1].sum():.0f}, request areas free at {x[:, 5].sum() / x[:, 1].sum():.0f}, log read at {x[:, 6].sum() / x[:, 1].sum():.0f}")
