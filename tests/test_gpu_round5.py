@@ -134,3 +134,31 @@ def test_bench_obs128_workload_alone(gpu):
     out = _bench(["--workload", "obs128", "--transitions", "200000", "--rollouts", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     assert out["parity_check"]["ok"] and out["config"]["p_log"] == "float16"
     assert out["roofline"]["bytes_per_candidate"] == 16 and out["encoder"]["argmax_equals_oracle_mlp"] is True
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torch_distributed_run(gpu):
+    """The driver's multi-GPU launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 2 ranks sharing this box's one GPU (gloo): bench.py is then ONE OF the ranks (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, no ranks of its own), rank 0 alone prints the line, `--gpus` must equal
+    WORLD_SIZE.  (The launcher is a child process of a process that never initialised the GPU.)"""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, OFFSIM_BENCH_TEST_SCALE="200")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--all-ranks-on-device0", "--dist-backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["collective"]["world"] == 2 and out["parity_check"]["ok"] and out["rollout_sharded"]["rollouts_per_gpu"] == 2048
+    # --gpus that disagrees with WORLD_SIZE is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
