@@ -278,7 +278,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     // Lanes 8..15 of a row are exact duplicates of lanes 0..7 inside the chain (same window entry, same draw, same key, same
     // stores): the row minimum then needs only the three DPP steps that stay inside eight lanes, and nothing is predicated.
     const uint32_t li4w = (li & 7u) * 4u;
-    const uint32_t win_rd_l = win_a + li4w;
     const uint32_t ring_a = rbase + RO_RING;
     const uint32_t lifield = ((li & 7u) + 1u) << ROWS_LIF;
 
@@ -419,7 +418,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     };
     uint32_t logh_a = rbase + RO_LOGH;  // ... and its side bytes (format B: local-row high bits of the steps logged in the long form)
     uint32_t z = 0;  // current state slot
-    uint32_t n_dry = 0, n_tie = 0, n_tick = 0, n_late = 0, n_miss = 0, n_req = 0;
+    uint32_t n_dry = 0, n_tie = 0, n_late = 0, n_miss = 0, n_req = 0;
     // refill: one outstanding request per lane
     uint32_t rq_s = 0, rq_p = 0, rq_n = 0;
     // reward pipeline, three ticks deep (R1: row index + discount, R2: reward, R3: in-order sums)
@@ -889,7 +888,6 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 #endif
         const uint32_t n = dead ? nlog_dead : ROWS_TICK;
         nlog_dead = 0;
-        n_tick++;
         scan_u32x4 in_a = {0u, 0u, 0u, 0u}, in_b = {0u, 0u, 0u, 0u};
         uint32_t v_ht = 0, v_gen = 0;
         uint32_t le = 0;
@@ -928,8 +926,8 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
                     }
                 }
             }
-            // Landing and hand-off, hand-written (round 4; the compiled form of the same steps -- ROWS_TICK_CXX -- took ~1400 of the
-            // tick's 1950 cycles): lane = step of the round that lands.  One batch of reads (descriptor, state, the eight staged
+            // Landing and hand-off, hand-written (round 4; the compiled form of the same steps took ~1400 of the tick's 1950
+            // cycles): lane = step of the round that lands.  One batch of reads (descriptor, state, the eight staged
             // digests), a second one (the state's window row and its end), the count of entries the head-aligned row holds, the
             // number k of staged digests that land -- the request was aimed at the window's end as it stands, its groups of four
             // have arrived, the row has room -- and k stores under the lane masks k > i; then the tick's log (lane = step), its
