@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--rng", default="pcg64", choices=["pcg64", "philox"],
                     help="rejection stream provider: pcg64 = NumPy's default_rng (the reference's numbers, the headline); philox = rocRAND's "
-                         "Philox4x32-10 device API in the generic kernel (another sample path: no oracle re-run, not the headline)")
+                         "Philox4x32-10 device engine in the same row-packed scan (another, equally valid sample path; the oracle's parity "
+                         "check replays the same stream; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing tests)")
@@ -136,10 +137,11 @@ def oracle_for(e):
     return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], p, e["steps"] == 0)
 
 
-def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_seed=1234):
+def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_seed=1234, rng="pcg64"):
     """The oracle on a few seeds of the SAME table the timed passes ran on (one rollout per host thread), against what the
     GPU returned for those seeds: accepted steps, candidates examined and completed episodes equal, value estimate
-    within 1e-5 (BASELINE.json north_star)."""
+    within 1e-5 (BASELINE.json north_star).  rng = "philox": the oracle's rejection stream replays rocRAND's Philox4x32-10 of the
+    same seed (the reference's rejection_sampling_rng is a plain attribute, psrs.py:20; pinned by tests/golden/philox_*.npz)."""
     import threading
     res = [None] * len(seeds)
 
@@ -150,6 +152,8 @@ def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_see
             o.set_rejection_seed(int(seeds[k]))
         else:
             o.reset_sampler(int(seeds[k]))
+        if rng == "philox":
+            o.set_rejection_philox(int(seeds[k]))
         res[k] = o.evalmc(10 ** 9, pi, gamma)
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(len(seeds))]
@@ -467,12 +471,12 @@ def run(a):
                 if record:
                     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                     e0.record()
-                env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots if a.rng == "pcg64" else None)
-                if a.rng == "philox":
-                    env.set_rejection_seeds(sd, provider="philox")
+                env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots, rejection=a.rng)
                 if record:
                     e1.record()
                 o = env.eval_mc(pi_slots, a.gamma)
+                if "_kernel" in o:
+                    local["kernel"] = o["_kernel"]  # (the generic kernel: a Philox job on a table the row-packed scan does not take)
                 if record:
                     e2.record()
                     ev.append(("reset_sampler", e0, e1))
@@ -508,7 +512,7 @@ def run(a):
         res = dict(elapsed=float(el_t[0]), steps_pass=float(tot[0]), cand_pass=float(tot[1]), t_scan=t_scan, t_reset=t_reset,
                    n_scan=sum(1 for k, _, _ in ev if k == "scan"), my_steps=float(acc["steps"].sum()), my_cand=float(acc["cand"].sum()),
                    est=est, acc={k: v.cpu().numpy() for k, v in acc.items()}, b_c=table.bytes_per_candidate, b_s=table.bytes_per_step,
-                   rows=table.N, tile=tile, variant=env_for(tile).scan_variant() if a.rng == "pcg64" else "k_eval_mc", seg=(table.min_seg, table.max_seg),
+                   rows=table.N, tile=tile, variant=local.get("kernel") or env_for(tile).scan_variant(), seg=(table.min_seg, table.max_seg),
                    resident=int(resident), hbm_free=int(free_b), hbm_total=int(total_b), ingest_s=t_ing, est_local=local.get("est"))
         _lib.check_async_faults()  # (the barrier synchronised: no kernel of these passes gave up a bounded wait)
         # bytes one pass of the sampler reset writes: every rollout's queue orders (6 / 5 bytes per position as candidate streams, 4 as
@@ -519,10 +523,10 @@ def run(a):
         # cycles and 100 MHz ticks of every chain wavefront, top-up and dry-row counters) -- what explains the roofline fraction of a
         # kernel that is bound by the latency of its dependent chains, not by HBM.  Row-packed kernel only.
         res["chain"] = None
-        if diag and res["variant"] == "k_eval_mc_rows" and a.rng == "pcg64" and n_timed > 0:
+        if diag and res["variant"] == "k_eval_mc_rows" and n_timed > 0:
             sd = sd_all[-tile:] if n_loc >= tile else np.concatenate([sd_all, np.repeat(sd_all[-1:], tile - n_loc)])
             env = env_for(len(sd))
-            env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots)
+            env.reset_sampler(sd, a.shuffle, shuffle_seed=1234, policy=pi_slots, rejection=a.rng)
             o = env.eval_mc(pi_slots, a.gamma, dbg=True)
             torch.cuda.synchronize()
             raw = o["dbg"].cpu().numpy()
@@ -676,11 +680,11 @@ def run(a):
         if test_scale > 1:
             out["test_scale"] = test_scale
         base = None
-        if not a.no_parity_check and a.shuffle != "table_order" and a.rng == "pcg64":  # (the reference has no unshuffled mode; the C oracle draws from PCG64)
+        if not a.no_parity_check and a.shuffle != "table_order":  # (the reference has no unshuffled mode)
             base = oracle_for(e)
             ps = [s for s in PARITY_SEEDS if s < R]
             got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ps}
-            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got, a.shuffle, 1234)
+            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got, a.shuffle, 1234, rng=a.rng)
             if not out["parity_check"]["ok"]:
                 sys.stderr.write(json.dumps(out["parity_check"]) + "\n")
                 raise SystemExit("bench.py: the GPU results differ from the oracle on this table -- no number is reported")

@@ -200,7 +200,10 @@ int offsim_step_server_start(const offsim_table *t, offsim_rollouts *ro, offsim_
  * (f64 / f32 by prob_mode; NULL for RESET), out3 = {row, status, popped}.  Returns OFFSIM_OK, or OFFSIM_SERVER_GONE (> 0) when the
  * server ended by itself before it saw the request -- the request stays posted: synchronise the server's stream, start it again (it
  * serves the posted request) and wait for seq_out == seq_in -- or OFFSIM_EHIP after max_spins polls (0: no bound) or, whatever
- * max_spins says, after OFFSIM_SERVER_ANSWER_SECONDS of wall-clock time (a dead server is reported in seconds, not minutes). */
+ * max_spins says, after OFFSIM_SERVER_ANSWER_SECONDS of wall-clock time spent with the server in state RUNNING (a dead server is
+ * reported in seconds, not minutes; a launch still queued on a shared device is not timed; the environment variable
+ * OFFSIM_SERVER_ANSWER_SECONDS overrides the bound, 0 = none).  After OFFSIM_EHIP the request is still posted (seq_in has moved): do
+ * not call again on this mailbox -- end the server (synchronise its stream or reset the device), clear the mailbox, start afresh. */
 #define OFFSIM_SERVER_GONE 1
 #define OFFSIM_SERVER_ANSWER_SECONDS 10.0
 int offsim_step_server_call(offsim_step_mailbox *mailbox, const void *p_new, int32_t n_actions, int32_t prob_mode, uint32_t cmd,
@@ -361,7 +364,9 @@ int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *stream);
  * lane operations on a stream of its own, synchronised: < 1 ms) and caches the verdict.  offsim_eval_mc_streams and the chunked shuffle
  * (offsim_shuffle_queues[_keys]_ws with a workspace, format C) call it themselves and return OFFSIM_EUNSUPPORTED on 0 -- never wrong
  * numbers; callers that want to route around it (to offsim_eval_mc_keys on permutations and a reset without workspace, as the Python
- * host mirror does) ask first. */
+ * host mirror does) ask first.  The first call on a device allocates and synchronises: those entry points therefore return OFFSIM_EINVAL,
+ * with nothing launched, when their stream is being captured and the verdict is not cached yet -- call this once outside the capture
+ * (the Python host mirror does, in _lib.require_device()). */
 int offsim_lds_order_ok(void);
 
 /* ---- headline scan on per-rollout candidate streams ------------------------------------------------------------
@@ -375,7 +380,7 @@ int offsim_lds_order_ok(void);
  *   OFFSIM_STREAMS_A   [T >> 32 : 21 | done : 1 | z_next : 10] = the high dword of the compiled key; loc is the whole local row:
  *                      every state has at most 65536 rows;
  *   OFFSIM_STREAMS_B   [T >> 37 : 16 | hi[6:2] : 5 | done : 1 | hi[1:0] : 2 | z_next : 8], hi = bits 16..22 of the local row:
- *                      states of up to 2^23 rows, at most 256 states.  (The coarser threshold only widens the band of draws that
+ *                      states of up to 2^23 rows, at most 255 states (a payload of all ones is not a digest).  (The coarser threshold only widens the band of draws that
  *                      are decided by the exact 53-bit look; results are the same bit for bit.)
  *   OFFSIM_STREAMS_C   [T >> 39 : 14 | hi[8:2] : 7 | done : 1 | hi[1:0] : 2 | z_next : 8], hi = bits 8..16 of the local row, loc = its
  *                      low byte: 5 bytes per queue position for states of up to 2^17 rows, at most 255 states -- a sixth less to keep
@@ -390,7 +395,7 @@ int offsim_lds_order_ok(void);
  *   offsim_eval_mc_keys on the same orders.  `keys` (offsim_compile_policy) is read only to decide digest ties
  *   exactly.  Strides are in elements; stride 0 = one order shared by all rollouts; loc == NULL = queues in table order
  *   (dig = dig32 itself, stride 0; format A).  ro->perm / perm_stride are ignored; ro->init_perm is used as everywhere else.
- *   n_slots <= 256; offsim_table.max_seg must be set: <= 65536 for format A, <= 2^23 for format B (OFFSIM_EUNSUPPORTED otherwise). */
+ *   n_slots <= 256 (255 for formats B and C); offsim_table.max_seg must be set: <= 65536 for format A, <= 2^23 for format B (OFFSIM_EUNSUPPORTED otherwise). */
 #define OFFSIM_STREAMS_A 0
 #define OFFSIM_STREAMS_B 1
 #define OFFSIM_STREAMS_C 2

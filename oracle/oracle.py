@@ -40,6 +40,8 @@ def lib():
         L.oracle_psrs_clone.argtypes = [C.c_void_p]
         L.oracle_psrs_reset_sampler.argtypes = [C.c_void_p, C.c_uint64]
         L.oracle_psrs_set_rejection_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_psrs_set_rejection_philox.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_philox_doubles.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, pd]
         L.oracle_psrs_get_orders.argtypes = [C.c_void_p, p64, p64, p64, p64]
         L.oracle_psrs_get_heads.argtypes = [C.c_void_p, p64, p64]
         L.oracle_psrs_n_keys.restype = C.c_int64
@@ -75,6 +77,13 @@ def rng_doubles(seed, n):
     """First n values of default_rng(seed).random()  (psrs.py:20,56)."""
     out = np.empty(n, np.float64)
     lib().oracle_rng_doubles(seed, n, _p(out, C.c_double))
+    return out
+
+
+def philox_doubles(seed, n, first=0):
+    """Draws first .. first + n - 1 of the Philox4x32-10 rejection stream of `seed` (u in (0, 1])."""
+    out = np.empty(n, dtype=np.float64)
+    lib().oracle_philox_doubles(int(seed), int(first), n, _p(out, C.c_double))
     return out
 
 
@@ -155,6 +164,10 @@ class OraclePSRS:
 
     def set_rejection_seed(self, seed):
         lib().oracle_psrs_set_rejection_seed(self._h, int(seed))
+
+    def set_rejection_philox(self, seed):
+        """env.rejection_sampling_rng = a replay of rocRAND's Philox4x32-10 stream of `seed` (include/offsim.h OFFSIM_STREAM_PHILOX)."""
+        lib().oracle_psrs_set_rejection_philox(self._h, int(seed))
 
     def orders(self):
         """(keys, key_off, queue rows CSR by key, init rows) after reset_sampler."""

@@ -175,6 +175,41 @@ void oracle_permutation(uint64_t seed, int64_t n, int64_t *out) {
 enum { ORACLE_REJECT_DEFAULT = 0, ORACLE_REJECT_NEVER = 1 };
 enum { ORACLE_PROB_F64 = 0, ORACLE_PROB_F32 = 1 };
 
+/* ------------------------------------------------------------------ */
+/* The second provider of the rejection stream (include/offsim.h       */
+/* OFFSIM_STREAM_PHILOX): Philox4x32-10 as rocRAND's device */
+/* API lays it out.  Third-party arithmetic, absent from the reference */
+/* tree: Random123's published rounds (multipliers 0xD2511F53 /        */
+/* 0xCD9E8D57, Weyl keys 0x9E3779B9 / 0xBB67AE85; ROCm 7.2's           */
+/* rocrand/rocrand_philox4x32_10.h), key = the 64-bit seed, counter =  */
+/* index of the group of four 32-bit outputs; a double is              */
+/* 2^-53 + (v1 | (v2 >> 11) << 32) * 2^-53 (rocrand_uniform.h), u in   */
+/* (0, 1].  Pinned by tests/golden/philox_*.npz: the reference's own   */
+/* PSRS.step with rejection_sampling_rng (psrs.py:20, a plain          */
+/* attribute) replaced by an object replaying this stream.             */
+/* ------------------------------------------------------------------ */
+static void philox4x32_10(uint64_t seed, uint64_t counter, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int round = 0; round < 10; round++) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)m1, n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)m0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+/* draw i of the stream seeded with `seed` */
+static double philox_double(uint64_t seed, uint64_t i) {
+    uint32_t w[4];
+    philox4x32_10(seed, i >> 1, w);
+    const uint32_t v1 = w[2 * (i & 1)], v2 = w[2 * (i & 1) + 1];
+    return 1.0 / 9007199254740992.0 + (double)((uint64_t)v1 | ((uint64_t)(v2 >> 11) << 32)) * (1.0 / 9007199254740992.0);
+}
+void oracle_philox_doubles(uint64_t seed, uint64_t first, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = philox_double(seed, first + (uint64_t)i);
+}
+
 typedef struct {
     /* the logged buffer, row-major as handed in (psrs.py:16-17) */
     int64_t N, nA;
@@ -193,6 +228,8 @@ typedef struct {
     int64_t *init_q; /* shuffled initial rows */
     int64_t n_init, init_head;
     pcg64_t rej;
+    int rej_philox; /* 1: the rejection stream replays Philox4x32-10 (seed rej_seed, next draw rej_i) instead of `rej` */
+    uint64_t rej_seed, rej_i;
     /* env state (psrs.py:32-37) */
     int has_state;
     int64_t cur_z;
@@ -294,6 +331,7 @@ static int64_t key_index(const psrs_t *p, int64_t z) {
  * the rejection stream, one for the init queue, one per state queue. */
 void oracle_psrs_reset_sampler(psrs_t *p, uint64_t seed) {
     pcg64_seed(&p->rej, seed); /* :20 */
+    p->rej_philox = 0;
     int64_t m = 0;
     for (int64_t i = 0; i < p->N; i++)
         if (p->t0[i]) p->init_q[m++] = i; /* :22 buffer order */
@@ -310,7 +348,18 @@ void oracle_psrs_reset_sampler(psrs_t *p, uint64_t seed) {
 }
 /* replace only the rejection stream (shared-order mode: reset_sampler(shuffle_seed)
  * then env.rejection_sampling_rng = default_rng(seed_r); psrs.py:20 is a plain attribute) */
-void oracle_psrs_set_rejection_seed(psrs_t *p, uint64_t seed) { pcg64_seed(&p->rej, seed); }
+void oracle_psrs_set_rejection_seed(psrs_t *p, uint64_t seed) {
+    pcg64_seed(&p->rej, seed);
+    p->rej_philox = 0;
+}
+/* env.rejection_sampling_rng = <replay of the Philox stream of `seed`> (make_golden.py's PhiloxReplay) */
+void oracle_psrs_set_rejection_philox(psrs_t *p, uint64_t seed) {
+    p->rej_philox = 1;
+    p->rej_seed = seed;
+    p->rej_i = 0;
+}
+/* self.rejection_sampling_rng.random()  (psrs.py:56) */
+static double rej_double(psrs_t *p) { return p->rej_philox ? philox_double(p->rej_seed, p->rej_i++) : pcg64_double(&p->rej); }
 
 void oracle_psrs_get_orders(const psrs_t *p, int64_t *keys, int64_t *key_off, int64_t *queue, int64_t *init_q) {
     memcpy(keys, p->keys, sizeof(int64_t) * (size_t)p->n_keys);
@@ -357,7 +406,7 @@ static int default_reject(psrs_t *p, const double *p_new, int prob_dtype, int64_
             if (q > M) M = q;
         }
         if (nan) M = NAN; /* ndarray.max() propagates NaN */
-        double u = pcg64_double(&p->rej);
+        double u = rej_double(p);
         float thr = (float)p_new[a] / (float)pl[a] / M;
         return (float)u > thr;
     }
@@ -369,7 +418,7 @@ static int default_reject(psrs_t *p, const double *p_new, int prob_dtype, int64_
         if (q > M) M = q;
     }
     if (nan) M = NAN;
-    double u = pcg64_double(&p->rej);
+    double u = rej_double(p);
     return u > p_new[a] / pl[a] / M;
 }
 

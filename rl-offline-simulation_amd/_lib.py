@@ -191,7 +191,11 @@ def require_device():
     import torch
     if not torch.cuda.is_available():
         raise OffsimError("no HIP device visible: the PSRS engine runs only on the GPU (no CPU fallback)")
-    return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    # the LDS lane-order guard runs its one-time self-test here, at table construction -- never inside a launch path, whose stream may
+    # be capturing (include/offsim.h, offsim_lds_order_ok)
+    lds_order_ok(dev)
+    return dev
 
 
 def stream_ptr():

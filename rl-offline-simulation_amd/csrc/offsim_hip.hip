@@ -267,6 +267,7 @@ static hipError_t allow_big_lds_fn(const void *fn, int bytes) {
 
 // wave-parallel exact Fisher-Yates (shuffle_wave.hpp), one workgroup per chain.  dig_out == NULL: orders as permutations of grouped
 // rows; otherwise the keyed form (digest stream + 16-bit local rows per queue position) for the state queues
+static int lds_order_ok_on(void *stream);  // the LDS lane-order guard as the launch paths ask it (defined beside offsim_lds_order_ok)
 static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t n_perm, uint32_t *perm_out, uint32_t *init_perm_out,
                           const uint32_t *dig32, uint32_t *dig_out, uint16_t *loc_out, hipStream_t st, bool big_segments_elsewhere = false) {
     const uint32_t max_seg = t->max_seg > 0 ? (uint32_t)(t->max_seg > 0xffffffffll ? 0xffffffffll : t->max_seg) : 0xffffffffu;
@@ -279,7 +280,7 @@ static int launch_shuffle(const offsim_table *t, const uint64_t *seeds, int32_t 
     // the applier's exchange form (one ds_mskor_rtn_b32 per lane instead of the tag round) where the LDS serves same-address lanes in
     // lane order (offsim_lds_order_ok: once per device); elsewhere the tag form -- same orders
     static const bool no_xchg = getenv("OFFSIM_SHUFFLE_XCHG") && atoi(getenv("OFFSIM_SHUFFLE_XCHG")) == 0;
-    const int okv = offsim_lds_order_ok();
+    const int okv = lds_order_ok_on(st);
     if (okv < 0) return okv;
     const uint32_t a_xchg = (okv == 1 && !no_xchg) ? 1u : 0u;
     if (!big_segments_elsewhere && (max_seg > SHUF_CAP16 || n0 > SHUF_CAP16)) {  // first: these chains are the long ones (or the chunked kernel has them)
@@ -437,7 +438,7 @@ static int shc_launch(const ShcPlan &p, const offsim_table *t, const uint64_t *s
                       uint32_t chains_above = SHUF_CAP16) {
     // the chunked kernel applies a group of messages with one ds_wrxchg_rtn_b32 per lane and relies on the LDS serving same-address
     // lanes in lane order: asked once per device (offsim_lds_order_ok)
-    { const int okv = offsim_lds_order_ok(); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "chunked shuffle: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): lend no workspace -- the in-place shuffle does not need it%s"); }
+    { const int okv = lds_order_ok_on(st); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "chunked shuffle: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): lend no workspace -- the in-place shuffle does not need it%s"); }
     uint32_t *hdr = (uint32_t *)workspace;  // [0] work counter, [1] number of long chains, [64 ..] their indices, longest first
     hipLaunchKernelGGL(k_chunk_worklist, dim3(1), dim3(256), 0, st, t->seg_off, t->n_slots, (uint32_t)(t->N0 > 0xffffffffll ? 0xffffffffll : t->N0), chains_above,
                        hdr + 64, hdr + 1, hdr);
@@ -496,7 +497,7 @@ extern "C" int offsim_shuffle_queues_keys_ws(const offsim_table *t, const uint64
     }
     if (big && format != OFFSIM_STREAMS_B)
         return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: a state has more than 65536 rows: stream format B (or offsim_shuffle_queues)%s");
-    if (big && (t->max_seg > (1ll << 23) || t->n_slots > 256)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 256 states%s");
+    if (big && (t->max_seg > (1ll << 23) || t->n_slots > 255)) return fail(OFFSIM_EUNSUPPORTED, "shuffle_queues_keys: format B holds 2^23 rows per state, 255 states%s");
     if (n_perm == 0) return OFFSIM_OK;
     hipStream_t st = (hipStream_t)stream;
     // the chains that do not fit LDS: the chunked kernel when the caller lent a workspace that holds at least one workgroup's pools,
@@ -1302,19 +1303,23 @@ extern "C" int offsim_step_server_call(offsim_step_mailbox *mb, const void *p_ne
     const uint32_t seq = m->seq_in + 1u;
     __atomic_store_n(&mb->seq_in2, seq, __ATOMIC_RELEASE);  // behind the payload
     __atomic_store_n(&mb->seq_in, seq, __ATOMIC_RELEASE);   // ... and last
-    // the wait is bounded by polls (max_spins) AND by wall-clock time: OFFSIM_SERVER_ANSWER_SECONDS, looked at every 65536 polls
+    // The wait is bounded by polls (max_spins) AND by wall-clock time, looked at every 65536 polls: OFFSIM_SERVER_ANSWER_SECONDS, or what
+    // the environment variable of that name says (0: no bound).  The clock runs only while the server is RUNNING: a launch that is still
+    // queued behind other work of a shared device (state STARTING, or not yet started) is not a dead server.
+    static const double answer_s = getenv("OFFSIM_SERVER_ANSWER_SECONDS") ? atof(getenv("OFFSIM_SERVER_ANSWER_SECONDS")) : OFFSIM_SERVER_ANSWER_SECONDS;
     uint64_t spins = 0;
     struct timespec t_start = {0, 0};
     while (__atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 1023u) == 0) {
-            if (m->state == OFFSIM_SERVER_EXITED && __atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) return OFFSIM_SERVER_GONE;
+            const uint32_t state = m->state;
+            if (state == OFFSIM_SERVER_EXITED && __atomic_load_n(&mb->seq_out, __ATOMIC_ACQUIRE) != seq) return OFFSIM_SERVER_GONE;
             if (max_spins && spins > max_spins) return fail(OFFSIM_EHIP, "step_server_call: the resident step server does not answer%s");
-            if ((spins & 65535u) == 0) {
+            if ((spins & 65535u) == 0 && answer_s > 0.0) {
                 struct timespec now;
                 clock_gettime(CLOCK_MONOTONIC, &now);
-                if (t_start.tv_sec == 0 && t_start.tv_nsec == 0) t_start = now;
-                else if ((double)(now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(now.tv_nsec - t_start.tv_nsec) > OFFSIM_SERVER_ANSWER_SECONDS)
+                if (state != OFFSIM_SERVER_RUNNING || (t_start.tv_sec == 0 && t_start.tv_nsec == 0)) t_start = now;
+                else if ((double)(now.tv_sec - t_start.tv_sec) + 1e-9 * (double)(now.tv_nsec - t_start.tv_nsec) > answer_s)
                     return fail(OFFSIM_EHIP, "step_server_call: the resident step server did not answer in time%s");
             }
         }
@@ -1740,7 +1745,7 @@ extern "C" int offsim_compile_digests(const offsim_table *t, const uint64_t *key
     if (rc) return rc;
     if (t->N > 0 && (!keys || !dig32_out)) return fail(OFFSIM_EINVAL, "compile_digests: bad argument%s");
     if (format != OFFSIM_STREAMS_A && format != OFFSIM_STREAMS_B && format != OFFSIM_STREAMS_C) return fail(OFFSIM_EINVAL, "compile_digests: bad format%s");
-    if (format == OFFSIM_STREAMS_B && t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format B holds 8-bit states%s");
+    if (format == OFFSIM_STREAMS_B && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format B holds 255 states (a payload of all ones is not a digest, csrc/scan_rows.hpp rows_format)%s");
     if (format == OFFSIM_STREAMS_C && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "compile_digests: format C holds 255 states%s");
     if (t->N == 0) return OFFSIM_OK;
     hipLaunchKernelGGL(k_key_digests, dim3((unsigned)((t->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, t->N, format, dig32_out);
@@ -1757,7 +1762,7 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_mc_streams: required output is NULL%s");
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: candidate windows support at most 256 states%s");
-    if (ro->rng_kind != OFFSIM_STREAM_PCG64) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: the compiled-policy scans draw from PCG64 only (use offsim_eval_mc)%s");
+    if (ro->rng_kind != OFFSIM_STREAM_PCG64 && ro->rng_kind != OFFSIM_STREAM_PHILOX) return fail(OFFSIM_EINVAL, "eval_mc_streams: unknown stream provider%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_streams: gamma_pow is NULL%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: queue positions are 32-bit (N < 2^32)%s");
     // positions inside a state's queue travel in 17-bit fields of the request descriptors and as 16-bit local rows (loc)
@@ -1765,11 +1770,11 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     if (t->N > 0 && (t->max_seg <= 0 || t->max_seg > (sm->format == OFFSIM_STREAMS_B ? (1ll << 23) : sm->format == OFFSIM_STREAMS_C ? (1ll << 17) : 65536ll)))
         return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: needs offsim_table.max_seg set and <= 65536 rows per state (format A) / 2^23 (B) / 2^17 (C)%s");
     if (sm->format != OFFSIM_STREAMS_A && !sm->loc) return fail(OFFSIM_EINVAL, "eval_mc_streams: formats B and C need the loc stream%s");
-    if (sm->format == OFFSIM_STREAMS_C && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: format C holds 255 states%s");
+    if (sm->format != OFFSIM_STREAMS_A && t->n_slots > 255) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: formats B and C hold 255 states%s");
     if (ro->R == 0) return OFFSIM_OK;
     // the tick takes its queue positions with one ds_add_rtn_u32 per rollout, lane = step, and relies on the LDS serving same-address
     // lanes in ascending lane order: checked once per device, refused (not silently wrong) where the property is absent
-    { const int okv = offsim_lds_order_ok(); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): use offsim_eval_mc_keys on permutations%s"); }
+    { const int okv = lds_order_ok_on(stream); if (okv < 0) return okv; if (okv == 0) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_streams: this device's LDS does not serve same-address lanes of one instruction in lane order (offsim_lds_order_ok): use offsim_eval_mc_keys on permutations%s"); }
     hipStream_t st = (hipStream_t)stream;
     const bool trace = out->trace_row || out->trace_pop;
     // four rollouts per wavefront; as many wavefronts per workgroup (<= 4) as the CU's 160 KiB of LDS hold regions for
@@ -1816,11 +1821,17 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
     // 0.899: the cliff is at the full device).  OFFSIM_ROWS_MINROOM overrides (A/B runs).
     static const int minroom_env = getenv("OFFSIM_ROWS_MINROOM") ? atoi(getenv("OFFSIM_ROWS_MINROOM")) : 0;
     const uint32_t rq_minroom = minroom_env > 0 ? (uint32_t)minroom_env : (int64_t)ro->R <= 12ll * cus ? 1u : 2u;  // (rollouts, whatever the shape of the launch)
+    // (the provider of the rejection stream is a template parameter: PCG64 = the reference's numbers, PHILOX = rocRAND's device API)
+#define LAUNCH_ROWS_RNG(TR, HL, FMT, RNG, THREADS)                                                                                 \
+    do {                                                                                                                           \
+        HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT, RNG>), 160 * 1024));                                                     \
+        hipLaunchKernelGGL((k_eval_mc_rows<TR, HL, FMT, RNG>), grid, dim3((unsigned)(THREADS)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, \
+                           n_gamma_pow, max_episodes, *out, seg_bytes, region, rq_minroom, (uint32_t)rpw);                                        \
+    } while (0)
 #define LAUNCH_ROWS(TR, HL, FMT, THREADS)                                                                                          \
     do {                                                                                                                           \
-        HIP_TRY(allow_big_lds((k_eval_mc_rows<TR, HL, FMT>), 160 * 1024));                                                          \
-        hipLaunchKernelGGL((k_eval_mc_rows<TR, HL, FMT>), grid, dim3((unsigned)(THREADS)), lds, st, *t, *ro, *sm, keys, gamma, gamma_pow, \
-                           n_gamma_pow, max_episodes, *out, seg_bytes, region, rq_minroom, (uint32_t)rpw);                                        \
+        if (ro->rng_kind == OFFSIM_STREAM_PHILOX) LAUNCH_ROWS_RNG(TR, HL, FMT, OFFSIM_STREAM_PHILOX, THREADS);                      \
+        else LAUNCH_ROWS_RNG(TR, HL, FMT, OFFSIM_STREAM_PCG64, THREADS);                                                            \
     } while (0)
     if (sm->format == OFFSIM_STREAMS_B) {
         if (trace) LAUNCH_ROWS(true, false, OFFSIM_STREAMS_B, waves * 64);
@@ -1836,6 +1847,7 @@ extern "C" int offsim_eval_mc_streams(const offsim_table *t, offsim_rollouts *ro
         else LAUNCH_ROWS(false, true, OFFSIM_STREAMS_A, waves * 128);
     }
 #undef LAUNCH_ROWS
+#undef LAUNCH_ROWS_RNG
     LAUNCH_CHECK();
     return OFFSIM_OK;
 }
@@ -1903,6 +1915,7 @@ __global__ void k_selftest_lds_order(uint32_t seed0, int trials, uint32_t n_addr
         }
         want = half ? 7000u + a : 3000u + a;
         last = want;
+        uint32_t last_other = half ? 3000u + a : 7000u + a;  // the word's OTHER half: its initial value, or what the last lane that exchanged it stored
         for (uint32_t j = 0; j < 64; j++) {
             const uint32_t aj = __shfl(a, j), hj = __shfl(half, j);
             const bool actj = __shfl((int)active, j);
@@ -1910,9 +1923,10 @@ __global__ void k_selftest_lds_order(uint32_t seed0, int trials, uint32_t n_addr
                 if (j < lane) want = j + 1u;
                 last = j + 1u;
             }
+            if (actj && aj == a && hj != half) last_other = j + 1u;
         }
         __syncthreads();
-        if (active && (got != want || ((cell[a] >> sh) & 0xffffu) != last)) nbad++;
+        if (active && (got != want || ((cell[a] >> sh) & 0xffffu) != last || ((cell[a] >> (16u - sh)) & 0xffffu) != last_other)) nbad++;
         __syncthreads();
     }
     if (nbad) atomicAdd(bad, nbad);
@@ -1933,7 +1947,7 @@ extern "C" int offsim_selftest_lds_atomic_order(int64_t *mismatches, void *strea
 // launch on a device and refuse (OFFSIM_EUNSUPPORTED) when the LDS of this part does not serve same-address lanes in lane order, instead
 // of returning wrong numbers; the host mirror routes such a device to the window kernel and the in-place shuffle.
 // OFFSIM_FORCE_LDS_ORDER_MISMATCH=1 makes the verdict "absent" (tests).
-extern "C" int offsim_lds_order_ok(void) {
+static int lds_order_verdict(hipStream_t caller, bool have_caller) {
     static int verdict[64];
     static bool init = false;
     static std::mutex mu;
@@ -1945,6 +1959,14 @@ extern "C" int offsim_lds_order_ok(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OFFSIM_EHIP, "lds_order_ok: no device%s");
     if (verdict[dev] >= 0) return verdict[dev];
+    // The first call on a device allocates, launches on a stream of its own and synchronises: not something an asynchronous entry point
+    // may do while its caller's stream is being captured into a graph (the allocation and the synchronisation would invalidate the
+    // capture).  Such a caller is told to ask once beforehand.
+    if (have_caller) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(caller, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(OFFSIM_EINVAL, "the stream is capturing and this device's LDS lane-order guard has not run yet: call offsim_lds_order_ok() once outside the capture%s");
+    }
     const char *force = getenv("OFFSIM_FORCE_LDS_ORDER_MISMATCH");
     if (force && atoi(force) == 1) return verdict[dev] = 0;
     unsigned long long *bad = nullptr, host = 0;
@@ -1963,6 +1985,9 @@ extern "C" int offsim_lds_order_ok(void) {
     if (!ok) return fail(OFFSIM_EHIP, "lds_order_ok: the self-test did not run%s");
     return verdict[dev] = host == 0 ? 1 : 0;
 }
+extern "C" int offsim_lds_order_ok(void) { return lds_order_verdict(nullptr, false); }
+// ... as the launch paths ask it: cached verdict, or the self-test now unless `stream` is capturing
+static int lds_order_ok_on(void *stream) { return lds_order_verdict((hipStream_t)stream, true); }
 
 // ------------------------------------------------------------------------------------------------
 // Encoders

@@ -151,6 +151,10 @@ __host__ __device__ constexpr RowsFormat rows_format(int fmt) {  // (the format 
     // the draw's top bits are below the threshold's, its low bits, all ones, only an upper bound -- and the one case that needs the exact
     // look is equal top bits; the two extra units of round 4's band sent three times as many looks to the compiled exact path: 9.0 k
     // per rollout on C4's shard at 14-bit thresholds.  Format A keeps its soaked 16 / 17 units of T21: 8e-6 of the looks either way.)
+    // With no bias a digest's PAYLOAD (its bits below the threshold) must never be all ones: a draw with equal top bits is laid down as
+    // top | paymask, and against such a digest the difference would be 0 -- "clear accept" -- where the exact look has to decide.  The
+    // payload's low byte is the next state: formats B and C are refused for more than 255 states (next state <= 254) by
+    // offsim_compile_digests, offsim_shuffle_queues_keys and offsim_eval_mc_streams.
     return fmt == OFFSIM_STREAMS_B   ? RowsFormat{16u, 0xffffu, 0x4ffu, 0xffu, 0u, 0u - (1u << 16), ROWS_LOG_KMASK | 0xfb00u, 16u}
            : fmt == OFFSIM_STREAMS_C ? RowsFormat{18u, 0x3ffffu, 0x4ffu, 0xffu, 0u, 0u - (1u << 18), ROWS_LOG_KMASK | 0x3fb00u, 8u}
                                      : RowsFormat{11u, 0x7ffu, 0x7ffu, 0x3ffu, ROWS_BIAS, ROWS_AMB, ROWS_LOG_KMASK, 16u};
@@ -220,6 +224,49 @@ __device__ __noinline__ uint64_t rows_exact53(const uint64_t *__restrict__ rng4,
     return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
 }
 
+// ---- the rocRAND provider (OFFSIM_STREAM_PHILOX, include/offsim.h) ----
+// Draw i of a rollout is rocrand_uniform_double of the engine (seed, subsequence 0) positioned on 32-bit output 2 i, i.e. u = k * 2^-53
+// with k = (v1 | (v2 >> 11) << 32) + 1 in [1, 2^53] (philox_k53, offsim_hip.hip).  The compiled keys hold T = the largest 53-bit k with
+// k * 2^-53 <= ratio (psrs.py:55-57 folded by offsim_compile_policy), so "accept iff k <= T" is the reference's rule for every k below
+// 2^53.  The one value beyond the 53 bits of a key, k = 2^53 (u = 1.0 exactly, probability 2^-53 per draw), is looked at as 2^53 - 1:
+// that differs from the rule only against an importance ratio of exactly 1 - 2^-53 (accepted here, rejected there); a ratio >= 1 or NaN
+// (T saturated) accepts both ways.  The generic kernels compare the double itself and have no such corner.
+// The engine itself is rocRAND's: philox4x32_10_engine::ten_rounds (rocrand/rocrand_philox4x32_10.h), reached through a derived class
+// because the public rocrand_init / rocrand pair indexes the engine's state by a run-time sub-position (private memory: scratch
+// loads in the helper's loop).  Key and counter are set as rocrand_init(seed, 0, 4 m) sets them -- key = the seed's two halves,
+// counter = m -- so block(seed, m) is the four 32-bit outputs 4 m .. 4 m + 3 of that engine, i.e. draws 2 m and 2 m + 1
+// (tests/test_gpu_round6.py holds it against philox_k53, the literal API, through the generic kernel and the reference's replayed stream).
+struct RowsPhilox : rocrand_device::philox4x32_10_engine {
+    __device__ __forceinline__ RowsPhilox() {}
+    __device__ __forceinline__ uint4 block(uint64_t seed, uint64_t m) {
+        const uint2 key = {(unsigned int)seed, (unsigned int)(seed >> 32)};
+        const uint4 ctr = {(unsigned int)m, (unsigned int)(m >> 32), 0u, 0u};
+        return this->ten_rounds(ctr, key);
+    }
+};
+__device__ __forceinline__ uint64_t rows_philox_clamp(uint32_t v1, uint32_t v2) {
+    const uint64_t k = ((uint64_t)v1 | ((uint64_t)(v2 >> 11) << 32)) + 1ull;
+    return k > 0x1fffffffffffffull ? 0x1fffffffffffffull : k;
+}
+// both draws of one Philox block: draws 2 m and 2 m + 1
+__device__ __forceinline__ void rows_philox_pair(uint64_t seed, uint64_t m, uint64_t &k0, uint64_t &k1) {
+    RowsPhilox e;
+    const uint4 v = e.block(seed, m);
+    k0 = rows_philox_clamp(v.x, v.y);
+    k1 = rows_philox_clamp(v.z, v.w);
+}
+__device__ __forceinline__ uint64_t rows_philox_k(uint64_t seed, uint64_t i) {
+    uint64_t k0, k1;
+    rows_philox_pair(seed, i >> 1, k0, k1);
+    return (i & 1ull) ? k1 : k0;
+}
+// the exact look's draw, by provider: index = draws of the stream before it
+template <int RNG>
+__device__ __forceinline__ uint64_t rows_exact_draw(const uint64_t *__restrict__ rng4, uint64_t index) {
+    if constexpr (RNG == OFFSIM_STREAM_PHILOX) return rows_philox_k(rng4[0], rng4[1] + index);
+    else return rows_exact53(rng4, index + 1u);
+}
+
 // HELPER = false: one wavefront does everything for its four rollouts (also the TRACE build).
 // HELPER = true : the workgroup has a second set of wavefronts, one per chain wavefront and (by the dispatch order of a
 //   workgroup's waves) on the same SIMD: the helper owns the rejection stream (it fills the draw ring ahead of the chain) and
@@ -233,7 +280,10 @@ __device__ __noinline__ uint64_t rows_exact53(const uint64_t *__restrict__ rng4,
 //   beyond the SY_GEN it has read, the helper never generates beyond SY_C + 240 of the 256 ring entries.  This relies on the
 //   LDS executing the DS instructions of ONE wavefront in issue order (data before flag); every wait is bounded
 //   (ROWS_SPIN_LIMIT) and ends the rollout with OFFSIM_ST_PROTOCOL instead of hanging the stream.
-template <bool TRACE, bool HELPER, int FMT>
+// RNG: the provider of the rejection stream (OFFSIM_STREAM_PCG64: NumPy's default_rng, the reference's numbers; OFFSIM_STREAM_PHILOX:
+//   rocRAND's Philox4x32-10 device API).  Only the generation of ring entries, the exact look's draw and the stream state written back
+//   differ: the ring holds the top 32 bits of the 53-bit draw either way.
+template <bool TRACE, bool HELPER, int FMT, int RNG = OFFSIM_STREAM_PCG64>
 __global__ void __launch_bounds__(HELPER ? 512 : 256)
     k_eval_mc_rows(offsim_table t, offsim_rollouts ro, offsim_streams sm, const uint64_t *__restrict__ keys, double gamma,
                    const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out,
@@ -312,9 +362,13 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
 
     // ---- rejection stream: lane j of the row owns draws j, j + 16, ... (jump-ahead); ring of k21 << 11 | 0x7ff ----
     const bool owns_draws = HELPER ? is_helper : true;
+    constexpr bool philox = RNG == OFFSIM_STREAM_PHILOX;
     U128 lane_state = u128(0, 0);
     U128 plus16 = u128(0, 0);
-    if (owns_draws) {
+    // Philox: the rng row is (seed, draws consumed so far, 0, 0); lanes 0..7 of a row each own one block = two draws per round of 16
+    // (lanes 8..15 repeat them: one instruction stream for the wavefront)
+    const uint64_t ph_seed = philox ? rng4[0] : 0ull, ph_c0 = philox ? rng4[1] : 0ull;
+    if (owns_draws && !philox) {
         const U128 base = u128(rng4[0], rng4[1]), inc = u128(rng4[2], rng4[3]);
         plus16 = pcg_jump(inc, 16).plus;
         lane_state = pcg_apply(pcg_jump(inc, (uint64_t)li + 1), base);  // yields draw li
@@ -322,9 +376,26 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
     const U128 mult16 = u128(0xb6a4239f3b315f84ull, 0xf6ef6d3d288c03c1ull);  // PCG multiplier ** 16 mod 2**128
     uint32_t gen = 0, c = 0;  // draws generated (HELPER chain: known to be generated) / consumed since kernel start
     auto gen16 = [&]() __attribute__((always_inline)) {
-        const uint32_t top = (uint32_t)(pcg_output(lane_state) >> 32);  // (the draw's top bits down to the threshold's resolution, ones below)
-        LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = top | ((1u << F.tshift) - 1u);
-        lane_state = add128(mul128(mult16, lane_state), plus16);
+        if constexpr (philox) {
+            // draws gen + 2 j and gen + 2 j + 1 of this launch (j = lane & 7) are draws ph_c0 + ... of the stream; an odd ph_c0 shifts
+            // the pairing by one: the block of stream draw d is d >> 1, so every lane works out the two blocks its two draws lie in
+            // only when the stream position is odd (a rollout that was stepped before: rare) -- the even case is one block
+            const uint64_t d0 = ph_c0 + (uint64_t)gen + 2u * (li & 7u);
+            uint64_t k0, k1;
+            if ((ph_c0 & 1ull) == 0ull) {
+                rows_philox_pair(ph_seed, d0 >> 1, k0, k1);
+            } else {
+                k0 = rows_philox_k(ph_seed, d0);
+                k1 = rows_philox_k(ph_seed, d0 + 1ull);
+            }
+            const uint32_t low = (1u << F.tshift) - 1u;
+            const scan_u32x2 pr = {(uint32_t)(k0 >> 21) | low, (uint32_t)(k1 >> 21) | low};
+            LV64(rbase + RO_RING + (((gen + 2u * (li & 7u)) & (ROWS_RING - 1u)) << 2)) = pr;  // (gen is a multiple of 16: the pair never wraps)
+        } else {
+            const uint32_t top = (uint32_t)(pcg_output(lane_state) >> 32);  // (the draw's top bits down to the threshold's resolution, ones below)
+            LV32(rbase + RO_RING + (((gen + li) & (ROWS_RING - 1u)) << 2)) = top | ((1u << F.tshift) - 1u);
+            lane_state = add128(mul128(mult16, lane_state), plus16);
+        }
         gen += 16u;
     };
     if (owns_draws) {
@@ -520,7 +591,7 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             bool ok = valid && k21 <= (dg >> F.tshift);
             if (ok && k21 == (dg >> F.tshift)) {  // tie at the digest's resolution: k53 of draw c+li against the full T
                 const uint32_t lc = lbase ? (loc_at(beg + cz + li) | (fmt_b ? rows_loc_hi(dg & F.paymask) << F.locbits : 0u)) : cz + li;
-                ok = !(rows_exact53(rng4, (uint64_t)c + li + 1u) > key_T(keys[beg + lc]));
+                ok = !(rows_exact_draw<RNG>(rng4, (uint64_t)c + li) > key_T(keys[beg + lc]));
             }
             const uint32_t fk = row_min16(ok ? ((li << 20) | (dg & F.paymask)) : 0xffffffffu);  // first accepted lane and its digest's payload
             if (fk == 0xffffffffu) {  // all of them rejected: consumed (one draw each)
@@ -1657,7 +1728,9 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
         if (li == 0u) {
             ro.init_cursor[r] = ic;
             ro.cur_slot[r] = (int32_t)z;
-            if (c) {
+            if (c && philox) {
+                ro.rng[4 * r + 1] = ph_c0 + c;  // (seed, draws consumed so far, 0, 0)
+            } else if (c) {
                 const U128 base = u128(rng4[0], rng4[1]), inc = u128(rng4[2], rng4[3]);
                 const U128 nb = pcg_apply(pcg_jump(inc, c), base);
                 ro.rng[4 * r + 0] = nb.hi;

@@ -109,11 +109,17 @@ class BatchedPSRS:
         L.check_async_faults()
 
     # -- PSRS.reset_sampler (psrs.py:19-30) for all rollouts --
-    def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None):
+    def reset_sampler(self, seeds, shuffle=SHUFFLE_PER_ROLLOUT, shuffle_seed=None, policy=None, rejection="pcg64"):
         """`policy` (optional, [n_slots,nA] f64): the tabular policy the following eval_mc calls will evaluate.  It changes no
         result; it lets the sampler reset write the queue orders as the candidate streams the row-packed scan reads
         sequentially (offsim_shuffle_queues_keys: digest + 16-bit local row per queue position) instead of as permutations.
-        (step / step_single / eval_td / the generic eval_mc need permutations and rebuild them from the streams on first use.)"""
+        (step / step_single / eval_td / the generic eval_mc need permutations and rebuild them from the streams on first use.)
+        `rejection`: the provider of the rejection stream the rollouts start with -- "pcg64" = default_rng(seed) (psrs.py:20, the
+        reference's numbers) or "philox" = rocRAND's Philox4x32-10 of the same seeds (set_rejection_seeds; the queue orders stay
+        NumPy's).  With "philox" the candidate streams are written whenever the row-packed scan can take the table at all: the
+        window kernel, which the speed rule of _streams_apply would otherwise prefer for some tables, draws from PCG64 only."""
+        if rejection not in ("pcg64", "philox"):
+            raise ValueError(rejection)
         self._quiesce()
         t, dev = self.table, self.table.device
         sd = seeds_tensor(seeds, dev)
@@ -124,7 +130,7 @@ class BatchedPSRS:
         self.state.rewind()
         self._streams = None
         self._perm_lazy = None
-        keyed = policy is not None and self._streams_apply(policy)
+        keyed = policy is not None and self._streams_apply(policy, whenever_able=rejection == "philox")
         if shuffle == SHUFFLE_PER_ROLLOUT:
             if self._init_perm_buf is None or self._init_perm_buf.shape[0] != self.R:
                 self._init_perm_buf = torch.empty((self.R, max(t.N0, 1)), dtype=torch.int32, device=dev)
@@ -165,6 +171,8 @@ class BatchedPSRS:
                 self._streams = self._table_order_streams(dig32, self._policy_key(policy))
         else:
             raise ValueError(shuffle)
+        if rejection == "philox":
+            self.set_rejection_seeds(sd, provider="philox")
 
     def _shuffle_workspace(self, n_orders=None):
         """Workspace of the chunked shuffle (states, or an init queue, of more than 65536 rows, csrc/shuffle_chunk.hpp): pools for up to
@@ -207,7 +215,7 @@ class BatchedPSRS:
         return self._ws
 
     # ---- candidate streams for the row-packed scan ----
-    def _streams_apply(self, policy):
+    def _streams_apply(self, policy, whenever_able=False):
         """Whether the candidate streams and the row-packed scan serve `policy` on this table: what offsim_eval_mc_streams covers (f64
         probabilities, the default reject rule, <= 256 states, states of up to 2^23 rows), and -- unless OFFSIM_SCAN_ROWS forces it --
         where that kernel is the faster one (below)."""
@@ -227,10 +235,10 @@ class BatchedPSRS:
         # to a kernel whose dry rows went through the C++ path; with the in-loop handler a low acceptance alone no longer decides.)
         # OFFSIM_SCAN_ROWS = 1 / 0 forces the one or the other.
         mode = os.environ.get("OFFSIM_SCAN_ROWS", "auto")
-        ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and 0 < t.max_seg <= (1 << 23) and t.N < 2 ** 32 - 1
-              and mode != "0")
+        ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= (256 if t.max_seg <= 65536 else 255) and 0 < t.max_seg <= (1 << 23)
+              and t.N < 2 ** 32 - 1 and mode != "0")  # (formats B and C: 255 states)
         ok = ok and L.lds_order_ok(t.device)  # (runtime guard of the tick's lane-ordered LDS atomic; never forced past)
-        if not ok or mode == "1":
+        if not ok or mode == "1" or whenever_able:
             return ok
         # Round 5 (tools/diag_scan.py, profiles/r05_diag_scan_c2_c3_c5.txt): L says nothing about a window that is FULL and still gives no
         # clear accept -- eight entries are all rejected with probability (1 - acceptance)^8: 0.2 % of the looks at 0.54, 6.5 % at
@@ -308,7 +316,7 @@ class BatchedPSRS:
         """Candidate streams from queue orders that exist as permutations (reset_sampler without `policy`): one gather, done
         for jobs of up to `max_entries` queue positions; bigger jobs pass `policy` to reset_sampler or run the window kernels."""
         t, st = self.table, self.state
-        if not self._streams_apply(policy) or (st.perm is None and self._perm_lazy == "streams"):
+        if not self._streams_apply(policy, whenever_able=st.rng_kind == L.STREAM_PHILOX) or (st.perm is None and self._perm_lazy == "streams"):
             return
         n_rows = 1 if (st.perm is None or st.perm_stride == 0) else self.R
         if n_rows * t.N > max_entries:
@@ -373,10 +381,11 @@ class BatchedPSRS:
     def set_rejection_seeds(self, seeds, provider="pcg64"):
         """Replace only the rejection streams (env.rejection_sampling_rng = ..., psrs.py:20 is a plain attribute).
         provider = "pcg64": default_rng(seed) -- the reference's numbers.  provider = "philox": rocRAND's Philox4x32-10 through its
-        device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by step / step_single / eval_td
-        and the generic eval_mc (the compiled-policy scans draw from PCG64 only); reset_sampler puts PCG64 back."""
+        device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by step / step_single / eval_td,
+        the generic eval_mc and the row-packed scan on candidate streams (the window kernel on permutations draws from PCG64 only);
+        reset_sampler puts PCG64 back unless it is told rejection="philox"."""
         self._quiesce()
-        sd = seeds_tensor(seeds, self.table.device)
+        sd = seeds.to(self.table.device) if isinstance(seeds, torch.Tensor) else seeds_tensor(seeds, self.table.device)
         assert sd.numel() == self.R, "one seed per rollout"
         if provider == "pcg64":
             seed_streams(sd, self.state.rng)
@@ -590,11 +599,12 @@ class BatchedPSRS:
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
                          trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
-        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256 and self.state.rng_kind == L.STREAM_PCG64
+        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256
+        philox = self.state.rng_kind == L.STREAM_PHILOX
         if fast is None:
             fast = can_fast
         if fast and not can_fast:
-            raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule, <= 256 states and the PCG64 stream")
+            raise L.OffsimError("the compiled-policy scan needs f64 probabilities, the default reject rule and <= 256 states")
         pkey = self._policy_key(pi_slots) if fast else None  # (once per call: a device tensor is copied to the host for it)
         if fast and not (self._streams is not None and self._streams["key"] == pkey):
             if self.state.perm is None and self._perm_lazy == "streams":
@@ -610,6 +620,14 @@ class BatchedPSRS:
             L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
                                                     gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys, sm)
+        elif fast and philox:
+            # the rocRAND provider runs in the row-packed scan (candidate streams: reset_sampler(policy=..., rejection="philox"), or
+            # orders small enough to derive them from) and in the generic kernel; the window kernel on permutations draws from PCG64 only
+            self._orders_for_generic()
+            L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
+                                            L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
+            o["_keepalive"] = (pi_d, gp)
+            o["_kernel"] = "k_eval_mc"
         elif fast:
             keys = self.compile_policy(pi_d)
             L.check(L.load().offsim_eval_mc_keys(C.byref(t.c), C.byref(self.state.c), L.ptr(keys), float(gamma), L.ptr(gp),
@@ -690,24 +708,47 @@ class BatchedPSRS:
         return self._keys
 
 
-def rollout_resident_bytes(table, keyed=True):
+def _workspace_reservation(table, free_b):
+    """(bytes the chunked shuffle's workspace will take out of `free_b`, whether at least one workgroup's pools fit): the rule of
+    BatchedPSRS._shuffle_workspace -- pools for up to 1024 persistent workgroups within 92 % of what is free and never its last 2 GiB."""
+    lib = L.load()
+    one = int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1))
+    if one <= 0 or max(table.max_seg, table.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
+        return 0, False
+    budget = max(0, min(int(free_b * 0.92), free_b - (2 << 30)))
+    return min(int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), budget), one <= budget
+
+
+def rollout_resident_bytes(table, keyed=True, fmt=None):
     """HBM one rollout keeps resident between reset_sampler and the scan: its queue orders (candidate streams: 4 + 2 bytes per queue
-    position; as permutations: 4), its init order, cursors and random-stream state."""
-    per_pos = 4 if not keyed else 5 if stream_format(table) == L.STREAMS_C else 6
+    position, 4 + 1 in format C; as permutations: 4), its init order, cursors and random-stream state.  `fmt`: the stream format the
+    environment will settle on (BatchedPSRS._stream_format: a format-C table falls back to B, 6 bytes, when the chunked shuffle's
+    workspace does not fit or the init queue is beyond 2^23 rows); default: decided here by the same rule on the free memory as it is."""
+    if fmt is None:
+        fmt = stream_format(table)
+        if keyed and fmt == L.STREAMS_C and table.device.type == "cuda":
+            fits = _workspace_reservation(table, torch.cuda.mem_get_info(table.device)[0])[1]
+            if table.N0 > (1 << 23) or not fits:
+                fmt = L.STREAMS_B
+    per_pos = 4 if not keyed else 5 if fmt == L.STREAMS_C else 6
     return int(table.N) * per_pos + int(table.N0) * 4 + int(table.n_slots) * 4 + 64
 
 
 def resident_rollouts(table, keyed=True, free_bytes=None):
     """How many rollouts' queue orders the free HBM of the table's device holds at once (shared by bench.py and evalmc_rollouts):
-    rollout_resident_bytes each, after 2 GiB for everything else of the job (policy keys, outputs, rebuilt permutations) and the
-    chunked shuffle's workspace -- pools for up to 1024 persistent workgroups, at most a tenth of what is free -- which
-    `_shuffle_workspace` allocates AFTER the stream buffers and which a table with chains above 65536 rows (or in stream format C,
-    where a missing workspace would cost the format) must still find room for.  Returns (rollouts, bytes per rollout, free, total)."""
+    rollout_resident_bytes each -- in the stream format the environment will really use -- after 2 GiB for everything else of the job
+    (policy keys, outputs, rebuilt permutations) and the chunked shuffle's workspace, reserved IN FULL by the rule that allocates it
+    (_workspace_reservation).  Order of the real allocations: a format-C table decides its format through `_shuffle_workspace`, i.e.
+    the workspace comes FIRST and the stream buffers after it; other tables allocate the stream buffers first and the workspace at
+    the first reset.  Either way both are accounted for here.  Returns (rollouts, bytes per rollout, free, total)."""
     free_b, total_b = torch.cuda.mem_get_info(table.device)
     if free_bytes is not None:
         free_b = int(free_bytes)
-    per = max(rollout_resident_bytes(table, keyed=keyed), 1)
-    ws_b = min(int(L.load().offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), free_b // 10)
+    ws_b, fits = _workspace_reservation(table, free_b)
+    fmt = stream_format(table)
+    if fmt == L.STREAMS_C and (table.N0 > (1 << 23) or not fits):
+        fmt = L.STREAMS_B
+    per = max(rollout_resident_bytes(table, keyed=keyed, fmt=fmt), 1)
     return int(max(0, free_b - (2 << 30) - ws_b) // per), per, int(free_b), int(total_b)
 
 

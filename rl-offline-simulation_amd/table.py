@@ -61,6 +61,8 @@ class TransitionTable:
         L.load()
         device = device or L.require_device()
         self.device = device
+        if torch.device(device).type == "cuda":
+            L.lds_order_ok(device)  # (the one-time LDS lane-order self-test of this device runs here, outside any launch path or capture)
         z = _dev(z, device, torch.int64)
         z_next = _dev(z_next, device, torch.int64)
         N = int(z.numel())

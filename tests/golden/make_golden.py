@@ -177,8 +177,73 @@ def psrs_fixture(name, inp, seeds, pi=None, gamma=0.99, p_new_step=None, reject_
     print(f"{name:28s} N={len(inp['z']):6d}  {os.path.getsize(path) / 1024:8.1f} KiB")
 
 
+# ---- the Philox stream provider (include/offsim.h OFFSIM_STREAM_PHILOX): the reference's own PSRS with
+# env.rejection_sampling_rng (a plain attribute, psrs.py:20) replaced by an object whose .random() replays rocRAND's
+# Philox4x32-10 -- restated here from /opt/rocm/include/rocrand/rocrand_philox4x32_10.h (Random123 rounds, key = seed, counter = index
+# of the group of four 32-bit outputs) and rocrand_uniform.h (two outputs -> (0, 1] double).  Queue orders stay NumPy's (seed).
+class PhiloxReplay:
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+    def __init__(self, seed):
+        self.key, self.i = (seed & 0xffffffff, (seed >> 32) & 0xffffffff), 0
+
+    def four(self, counter):
+        c = [counter & 0xffffffff, (counter >> 32) & 0xffffffff, 0, 0]
+        k0, k1 = self.key
+        for _ in range(10):
+            m0, m1 = self.M0 * c[0], self.M1 * c[2]
+            c = [((m1 >> 32) ^ c[1] ^ k0) & 0xffffffff, m1 & 0xffffffff, ((m0 >> 32) ^ c[3] ^ k1) & 0xffffffff, m0 & 0xffffffff]
+            k0, k1 = (k0 + self.W0) & 0xffffffff, (k1 + self.W1) & 0xffffffff
+        return c
+
+    def random(self):
+        w = self.four(self.i >> 1)[2 * (self.i & 1): 2 * (self.i & 1) + 2]  # 32-bit outputs 2 i and 2 i + 1
+        self.i += 1
+        return 2.0 ** -53 + float(w[0] | ((w[1] >> 11) << 32)) * 2.0 ** -53
+
+
+def philox_fixtures():
+    """philox_iid_2k.npz (step protocol + evalMC, 25 states x 5 actions) and philox_iid_50k.npz (evalMC on the 50 k-row, 162-state,
+    2-action log of iid_50k_s162_a2: the shape of the headline job).  `python tests/golden/make_golden.py philox` writes only these."""
+    pi25 = synth.dirichlet_policy(25, 5)
+    inp = case_inputs(synth.synth_iid(2000, 25, 5, seed=20221107))
+    out = {("in_" + k): v for k, v in inp.items()}
+    out["seeds"], out["pi"], out["gamma"], out["p_new_step"] = np.array([0, 7, 2 ** 40 + 5], np.int64), pi25, np.float64(0.99), np.full(5, 0.2)
+    out["first_draws"] = np.zeros((3, 8))
+    for k, s in enumerate(out["seeds"]):
+        g = PhiloxReplay(int(s))
+        out["first_draws"][k] = [g.random() for _ in range(8)]
+    h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+    for s in out["seeds"]:
+        s = int(s)
+        for proto in ("step", "mc"):
+            h.env.reset_sampler(seed=s)
+            h.env.rejection_sampling_rng = PhiloxReplay(s)
+            res = run_step_protocol(h, out["p_new_step"]) if proto == "step" else run_evalmc(h, pi25, 0.99, 10 ** 9)
+            for k, v in res.items():
+                out[f"s{s}_{proto}_{k}"] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "philox_iid_2k.npz"), **out)
+    print(f"{'philox_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's{int(s)}_mc_rows']) for s in out['seeds']]}")
+
+    # the 50 k-row case: inputs are those of iid_50k_s162_a2.npz (same generator call; not stored twice), outputs under the Philox stream
+    inp = case_inputs(synth.synth_iid(50000, 162, 2, seed=20221107))
+    pi162 = synth.dirichlet_policy(162, 2)
+    out = dict(seeds=np.array([0, 7, 2 ** 40 + 5], np.int64), pi=pi162, gamma=np.float64(0.99), inputs_of=np.array("iid_50k_s162_a2"))
+    h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
+    for s in out["seeds"]:
+        s = int(s)
+        h.env.reset_sampler(seed=s)
+        h.env.rejection_sampling_rng = PhiloxReplay(s)
+        for k, v in run_evalmc(h, pi162, 0.99, 10 ** 9).items():
+            out[f"s{s}_mc_{k}"] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "philox_iid_50k.npz"), **out)
+    print(f"{'philox_iid_50k':28s} N={len(inp['z']):6d}  steps {[len(out[f's{int(s)}_mc_rows']) for s in out['seeds']]}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["philox"]:
+        return philox_fixtures()
 
     # ---- RNG layer (third-party arithmetic the path relies on: psrs.py:20,23,30,56) ----
     seeds = [0, 1, 2, 3, 7, 42, 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 5, 2 ** 63 + 11]
@@ -351,48 +416,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "td2_iid_2k.npz"), **out)
     print(f"{'td2_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's0_{t}_rows']) for t in ('sched', 'ties', 'ties_sched', 'greedy', 'soft', 'saveq', 'es_sched')]}")
 
-    # ---- 11c. the Philox stream provider (include/offsim.h OFFSIM_STREAM_PHILOX): the reference's own PSRS with
-    # env.rejection_sampling_rng (a plain attribute, psrs.py:20) replaced by an object whose .random() replays rocRAND's
-    # Philox4x32-10 -- restated here from /opt/rocm/include/rocrand/rocrand_philox4x32_10.h (Random123 rounds, key = seed, counter = index
-    # of the group of four 32-bit outputs) and rocrand_uniform.h (two outputs -> (0, 1] double).  Queue orders stay NumPy's (seed).
-    class PhiloxReplay:
-        M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
-
-        def __init__(self, seed):
-            self.key, self.i = (seed & 0xffffffff, (seed >> 32) & 0xffffffff), 0
-
-        def four(self, counter):
-            c = [counter & 0xffffffff, (counter >> 32) & 0xffffffff, 0, 0]
-            k0, k1 = self.key
-            for _ in range(10):
-                m0, m1 = self.M0 * c[0], self.M1 * c[2]
-                c = [((m1 >> 32) ^ c[1] ^ k0) & 0xffffffff, m1 & 0xffffffff, ((m0 >> 32) ^ c[3] ^ k1) & 0xffffffff, m0 & 0xffffffff]
-                k0, k1 = (k0 + self.W0) & 0xffffffff, (k1 + self.W1) & 0xffffffff
-            return c
-
-        def random(self):
-            w = self.four(self.i >> 1)[2 * (self.i & 1): 2 * (self.i & 1) + 2]  # 32-bit outputs 2 i and 2 i + 1
-            self.i += 1
-            return 2.0 ** -53 + float(w[0] | ((w[1] >> 11) << 32)) * 2.0 ** -53
-
-    inp = iid2k
-    out = {("in_" + k): v for k, v in inp.items()}
-    out["seeds"], out["pi"], out["gamma"], out["p_new_step"] = np.array([0, 7, 2 ** 40 + 5], np.int64), pi25, np.float64(0.99), np.full(5, 0.2)
-    out["first_draws"] = np.array([[PhiloxReplay(int(s)).random() for _ in range(1)] + [0.0] * 7 for s in out["seeds"]])
-    for k, s in enumerate(out["seeds"]):
-        g = PhiloxReplay(int(s))
-        out["first_draws"][k] = [g.random() for _ in range(8)]
-    h = Harness(inp["z"], inp["a"], inp["r"], inp["z_next"], inp["done"], inp["p_log"], inp["t0"])
-    for s in out["seeds"]:
-        s = int(s)
-        for proto in ("step", "mc"):
-            h.env.reset_sampler(seed=s)
-            h.env.rejection_sampling_rng = PhiloxReplay(s)
-            res = run_step_protocol(h, out["p_new_step"]) if proto == "step" else run_evalmc(h, pi25, 0.99, 10 ** 9)
-            for k, v in res.items():
-                out[f"s{s}_{proto}_{k}"] = np.array(v)
-    np.savez_compressed(os.path.join(OUT, "philox_iid_2k.npz"), **out)
-    print(f"{'philox_iid_2k':28s} N={len(inp['z']):6d}  steps {[len(out[f's{int(s)}_mc_rows']) for s in out['seeds']]}")
+    # ---- 11c. the Philox stream provider: philox_fixtures() above ----
+    philox_fixtures()
 
     # ---- 12. QueueEvaluator_impl (queue_evaluator.py:90-131): (z, a)-keyed queues, no rejection.  The module imports gym at
     # the top, so only the class (numpy + itertools) is compiled from the reference file, unmodified, in memory.

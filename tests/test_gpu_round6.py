@@ -1,0 +1,157 @@
+"""Round-6 GPU tests: the rocRAND provider of the rejection stream (OFFSIM_STREAM_PHILOX) in the ROW-PACKED scan (csrc/scan_rows.hpp:
+the helper wavefront fills the draw ring from philox4x32_10_engine::ten_rounds) -- against the reference's own PSRS with a replayed
+Philox stream (tests/golden/philox_*.npz), against the oracle fed the same stream, and against the generic kernel (the literal
+rocrand_init / rocrand device API) at stream positions of either parity."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import load
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from rl_offline_simulation_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+def _table(d, gpu):
+    from rl_offline_simulation_amd.table import TransitionTable
+    src = load(str(d["inputs_of"])) if "inputs_of" in d.files else d
+    return TransitionTable(src["in_z"], src["in_a"], src["in_r"], src["in_z_next"], src["in_done"], src["in_p_log"], src["in_t0"], device=gpu)
+
+
+@pytest.mark.parametrize("name", ["philox_iid_2k", "philox_iid_50k"])
+def test_philox_in_the_row_packed_scan_against_the_reference_with_a_replayed_stream(name, gpu):
+    """reset_sampler(policy=pi, rejection="philox") writes the candidate streams and hands the rollouts rocRAND's stream; eval_mc then
+    runs k_eval_mc_rows<.., OFFSIM_STREAM_PHILOX>.  Traced launch (single wavefront): accepted rows and candidates popped per step, every
+    episode's return (bit-exact f64) and length as the reference served them under the replayed stream.  Untraced launch (helper
+    wavefronts: the product's form): the same counts and the in-order sum of returns."""
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    d = load(name)
+    table = _table(d, gpu)
+    seeds = [int(s) for s in d["seeds"]]
+    pi = table.policy_slots(d["pi"])
+    env = BatchedPSRS(table, len(seeds))
+    for traced in (True, False):
+        env.reset_sampler(seeds, policy=pi, rejection="philox")
+        assert env.scan_variant() == "k_eval_mc_rows"
+        o = env.eval_mc(pi, float(d["gamma"]), ep_cap=table.N0 + 1, trace_cap=(table.N + 1) if traced else 0)
+        torch.cuda.synchronize()
+        assert "_kernel" not in o  # (not the generic kernel)
+        for i, s in enumerate(seeds):
+            rows, pops = d[f"s{s}_mc_rows"], d[f"s{s}_mc_popped"]
+            n = int(o["steps"][i])
+            assert n == len(rows) and int(o["cand"][i]) == int(pops.sum()), (s, traced)
+            if traced:
+                assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), rows)
+                assert np.array_equal(o["trace_pop"][i, :n].cpu().numpy(), pops[:n])
+            ne, nl = int(o["n_ep"][i]), int(o["n_len"][i])
+            assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), d[f"s{s}_mc_Gs"])
+            assert np.array_equal(o["ep_len"][i, :nl].cpu().numpy(), d[f"s{s}_mc_lengths"])
+            acc = 0.0
+            for g in d[f"s{s}_mc_Gs"]:
+                acc += float(g)
+            assert float(o["sum_g"][i]) == acc
+            # the stream state written back: (seed, draws consumed so far, 0, 0)
+            assert [int(x) for x in env.state.rng[i].cpu().numpy().view(np.uint64)] == [s, int(pops.sum()), 0, 0]
+
+
+def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed):
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(N, nS, nA, seed=seed)
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], e["steps"] == 0, device=gpu)
+    pi_np = synth.dirichlet_policy(nS, nA)
+    pi = table.policy_slots(pi_np)
+    seeds = [1000 + 3 * i for i in range(R)]
+    outs = []
+    for rows in (True, False):
+        env = BatchedPSRS(table, R)
+        env.reset_sampler(seeds, policy=pi if rows else None, rejection="philox")
+        if pre_steps:  # a few steps through the generic kernel first: the rollouts enter the scan at stream positions of either parity
+            env.reset()
+            p = np.tile(np.full(nA, 1.0 / nA), (R, 1))
+            for _ in range(pre_steps):
+                env.step(p)
+            assert len(set((env.state.rng[:, 1].cpu().numpy() & 1).tolist())) == 2
+        o = env.eval_mc(pi, 0.97, ep_cap=64, fast=None if rows else False)
+        torch.cuda.synchronize()
+        assert ("_kernel" not in o and env.scan_variant() == "k_eval_mc_rows") if rows else True
+        outs.append({k: o[k].cpu().numpy() for k in ("steps", "cand", "n_ep", "n_len", "sum_g", "status", "ep_g", "ep_len")} |
+                    {"rng": env.state.rng.cpu().numpy()})
+    a, b = outs
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["steps"].min() > 100
+    return a
+
+
+def test_philox_rows_kernel_equals_the_generic_kernel(gpu):
+    """block(seed, m) of csrc/scan_rows.hpp (the engine's ten_rounds through a derived class) against philox_k53 (rocrand_init /
+    rocrand, the literal device API, in k_eval_mc): 64 rollouts on a 200 k-row table, every count, episode and sum equal, and the
+    stream positions written back."""
+    _philox_rows_vs_generic(gpu, 200000, 162, 2, 64, 0, seed=5)
+
+
+def test_philox_rows_kernel_from_odd_and_even_stream_positions(gpu):
+    """A rollout that was stepped before enters the scan at any stream position: an odd one pairs the draws across Philox blocks."""
+    _philox_rows_vs_generic(gpu, 60000, 30, 3, 32, 3, seed=6)
+
+
+def test_philox_against_the_oracle_with_the_same_stream_at_a_million_rows(gpu):
+    """What bench.py --rng philox checks on four seeds, at a size the oracle finishes in seconds: 1 M rows, 162 states, 2 actions."""
+    from oracle import oracle as O
+    from rl_offline_simulation_amd import synth
+    from rl_offline_simulation_amd.table import TransitionTable
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    e = synth.synth_iid(1000000, 162, 2, seed=20221107)
+    t0 = e["steps"] == 0
+    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0, device=gpu)
+    pi_np = synth.dirichlet_policy(162, 2)
+    pi = table.policy_slots(pi_np)
+    seeds = list(range(16))
+    env = BatchedPSRS(table, len(seeds))
+    env.reset_sampler(seeds, policy=pi, rejection="philox")
+    o = env.eval_mc(pi, 0.99)
+    torch.cuda.synchronize()
+    assert env.scan_variant() == "k_eval_mc_rows" and "_kernel" not in o
+    ora = O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+    for i in (0, 5, 15):
+        ora.reset_sampler(seeds[i])
+        ora.set_rejection_philox(seeds[i])
+        ref = ora.evalmc(10 ** 9, pi_np, 0.99)
+        assert int(o["steps"][i]) == ref["steps"] and int(o["cand"][i]) == ref["candidates"] and int(o["n_ep"][i]) == len(ref["Gs"])
+        acc = 0.0
+        for g in ref["Gs"]:
+            acc += float(g)
+        assert float(o["sum_g"][i]) == acc
+
+
+@pytest.mark.parametrize("variant", ["rows_single", "waves1", "rpw2", "auto"])
+def test_philox_tests_under_the_other_launch_shapes(variant):
+    """The Philox tests of this file again with the single-wavefront form of the kernel, one chain wavefront per workgroup, two
+    rollouts per chain wavefront, and the launcher's own choice (switches read once per process: child processes)."""
+    env = dict(os.environ)
+    if variant == "rows_single":
+        env["OFFSIM_ROWS_HELPER"] = "0"
+    elif variant == "waves1":
+        env["OFFSIM_ROWS_WAVES"] = "1"
+    elif variant == "rpw2":
+        env["OFFSIM_ROWS_PER_WAVE"] = "2"
+    else:
+        env.pop("OFFSIM_ROWS_WAVES", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "philox and not other_launch_shapes"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -112,6 +112,44 @@ def test_psrs_case(name):
                     assert abs(res["Gs"].mean() - float(d[f"s{s}_mc_mean"])) <= 1e-12
 
 
+@pytest.mark.parametrize("name", ["philox_iid_2k", "philox_iid_50k"])
+def test_philox_replay_stream(name):
+    """The oracle's second provider of the rejection stream (Philox4x32-10 as rocRAND's device API lays it out, include/offsim.h
+    OFFSIM_STREAM_PHILOX): pinned on what the reference's own PSRS served with rejection_sampling_rng replaying that stream
+    (tests/golden/make_golden.py philox_fixtures)."""
+    d = load(name)
+    src = load(str(d["inputs_of"])) if "inputs_of" in d.files else d
+    env = make_oracle(src)
+    for i, s in enumerate(d["seeds"]):
+        s = int(s)
+        if "first_draws" in d.files:
+            assert np.array_equal(O.philox_doubles(s, 8), d["first_draws"][i])
+            assert np.array_equal(O.philox_doubles(s, 5, first=3), d["first_draws"][i][3:])
+        env.reset_sampler(s)
+        env.set_rejection_philox(s)
+        res = env.evalmc(10 ** 9, d["pi"], float(d["gamma"]), O.PROB_F64, O.REJECT_DEFAULT, trace_cap=env.N)
+        assert np.array_equal(res["Gs"], d[f"s{s}_mc_Gs"])
+        assert np.array_equal(res["lengths"], d[f"s{s}_mc_lengths"])
+        assert np.array_equal(res["trace_rows"], d[f"s{s}_mc_rows"])
+        assert np.array_equal(res["trace_popped"], d[f"s{s}_mc_popped"][: len(res["trace_popped"])])
+        if "p_new_step" in d.files:  # the step protocol (one fixed p_new, reset on done)
+            env.reset_sampler(s)
+            env.set_rejection_philox(s)
+            rows, popped = [], []
+            alive = env.reset() is not None
+            while alive:
+                row, n = env.step(d["p_new_step"])
+                rows.append(-1 if row is None else row)
+                popped.append(n)
+                if row is None:
+                    break
+                if src["in_done"][row]:
+                    alive = env.reset() is not None
+            assert np.array_equal(rows, d[f"s{s}_step_rows"]) and np.array_equal(popped, d[f"s{s}_step_popped"])
+        env.reset_sampler(s)  # ... and reset_sampler puts the PCG64 stream back (psrs.py:20)
+        assert env.evalmc(10 ** 9, d["pi"], float(d["gamma"]))["candidates"] != res["candidates"] or name != "philox_iid_50k"
+
+
 def test_cartpole_box_encoder():
     d = load("enc_cartpole_box")
     assert np.array_equal(O.cartpole_encode(d["obs"]), d["z"])
