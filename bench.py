@@ -37,6 +37,14 @@ if ROOT not in sys.path:
 
 PARITY_SEEDS = (0, 1, 2047, 4095)
 _REAL_STDOUT = sys.stdout
+_T0 = time.perf_counter()
+
+
+def _phase(msg):
+    """OFFSIM_BENCH_TRACE=1: wall-clock stamps of the command's phases on stderr (where its host time goes)."""
+    if os.environ.get("OFFSIM_BENCH_TRACE"):
+        sys.stderr.write(f"[bench +{time.perf_counter() - _T0:7.2f} s] {msg}\n")
+        sys.stderr.flush()
 
 
 def parse():
@@ -137,46 +145,60 @@ def oracle_for(e):
     return O.OraclePSRS(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], p, e["steps"] == 0)
 
 
-def parity_check(base, pi, gamma, seeds, got, shuffle="per_rollout", shuffle_seed=1234, rng="pcg64"):
-    """The oracle on a few seeds of the SAME table the timed passes ran on (one rollout per host thread), against what the
-    GPU returned for those seeds: accepted steps, candidates examined and completed episodes equal, value estimate
-    within 1e-5 (BASELINE.json north_star).  rng = "philox": the oracle's rejection stream replays rocRAND's Philox4x32-10 of the
-    same seed (the reference's rejection_sampling_rng is a plain attribute, psrs.py:20; pinned by tests/golden/philox_*.npz)."""
-    import threading
-    res = [None] * len(seeds)
+class OracleRun:
+    """The oracle on a few seeds of the SAME table the timed passes run on, started on host threads as soon as the log exists -- it needs
+    nothing of the GPU's, so it works beside the timed passes instead of after them (round 6: the default command spent 15 s of host time
+    here, one configuration after the other) -- and compared with what the GPU returned once both are done (`check`)."""
 
-    def work(k):
-        o = base.clone()
-        if shuffle == "shared":  # one queue order for all rollouts, per-rollout rejection streams (psrs.py:20 is a plain attribute)
-            o.reset_sampler(int(shuffle_seed))
-            o.set_rejection_seed(int(seeds[k]))
-        else:
-            o.reset_sampler(int(seeds[k]))
-        if rng == "philox":
-            o.set_rejection_philox(int(seeds[k]))
-        res[k] = o.evalmc(10 ** 9, pi, gamma)
+    def __init__(self, e, pi, gamma, seeds, shuffle="per_rollout", shuffle_seed=1234, rng="pcg64"):
+        import threading
+        self.seeds, self.res, self.base, self.err = [int(s) for s in seeds], [None] * len(seeds), None, None
 
-    th = [threading.Thread(target=work, args=(k,)) for k in range(len(seeds))]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    ok, worst = True, 0.0
-    rows = []
-    for k, s in enumerate(seeds):
-        ref = res[k]
-        n_ep = len(ref["Gs"])
-        v_ref = float(ref["Gs"].mean()) if n_ep else float("nan")
-        g = got[int(s)]
-        v = g["sum_g"] / g["n_ep"] if g["n_ep"] else float("nan")
-        err = abs(v - v_ref) if n_ep else 0.0
-        same = (g["steps"] == ref["steps"] and g["cand"] == ref["candidates"] and g["n_ep"] == n_ep and err <= 1e-5)
-        ok &= bool(same)
-        worst = max(worst, err)
-        rows.append({"seed": int(s), "steps": ref["steps"], "candidates": ref["candidates"], "episodes": n_ep, "value": v_ref, "match": bool(same)})
-    return {"seeds": [int(s) for s in seeds], "ok": bool(ok), "max_abs_value_err": worst, "tolerance": 1e-5, "table_rows": int(base.N),
-            "checked": "accepted steps, candidates examined, completed episodes equal; |sum_g/n_ep - mean(Gs)| <= 1e-5; oracle/psrs_oracle.c, "
-                       "one full rollout per seed on this rank's table", "oracle": rows}
+        def work(k):
+            o = self.base.clone()
+            if shuffle == "shared":  # one queue order for all rollouts, per-rollout rejection streams (psrs.py:20 is a plain attribute)
+                o.reset_sampler(int(shuffle_seed))
+                o.set_rejection_seed(self.seeds[k])
+            else:
+                o.reset_sampler(self.seeds[k])
+            if rng == "philox":  # env.rejection_sampling_rng = a replay of rocRAND's Philox4x32-10 of the same seed (tests/golden/philox_*.npz)
+                o.set_rejection_philox(self.seeds[k])
+            self.res[k] = o.evalmc(10 ** 9, pi, gamma)
+
+        def lead():
+            try:
+                self.base = oracle_for(e)
+                th = [threading.Thread(target=work, args=(k,)) for k in range(len(self.seeds))]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+            except BaseException as ex:  # (re-raised by check)
+                self.err = ex
+
+        self.thread = threading.Thread(target=lead)
+        self.thread.start()
+
+    def check(self, got):
+        """Accepted steps, candidates examined and completed episodes equal, value estimate within 1e-5 (BASELINE.json north_star)."""
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        ok, worst, rows = True, 0.0, []
+        for k, s in enumerate(self.seeds):
+            ref = self.res[k]
+            n_ep = len(ref["Gs"])
+            v_ref = float(ref["Gs"].mean()) if n_ep else float("nan")
+            g = got[int(s)]
+            v = g["sum_g"] / g["n_ep"] if g["n_ep"] else float("nan")
+            err = abs(v - v_ref) if n_ep else 0.0
+            same = (g["steps"] == ref["steps"] and g["cand"] == ref["candidates"] and g["n_ep"] == n_ep and err <= 1e-5)
+            ok &= bool(same)
+            worst = max(worst, err)
+            rows.append({"seed": int(s), "steps": ref["steps"], "candidates": ref["candidates"], "episodes": n_ep, "value": v_ref, "match": bool(same)})
+        return {"seeds": self.seeds, "ok": bool(ok), "max_abs_value_err": worst, "tolerance": 1e-5, "table_rows": int(self.base.N),
+                "checked": "accepted steps, candidates examined, completed episodes equal; |sum_g/n_ep - mean(Gs)| <= 1e-5; oracle/psrs_oracle.c, "
+                           "one full rollout per seed on this rank's table (host threads beside the timed passes)", "oracle": rows}
 
 
 def cpu_baseline(base, pi, gamma, budget_s, cap):
@@ -408,13 +430,17 @@ def run(a):
     test_scale = max(1, int(os.environ.get("OFFSIM_BENCH_TEST_SCALE", "1")))
     a.transitions //= test_scale
     # strong: every rank derives its shard from the same log; weak: shard g is its own log, generated from seed 20221107 + g
+    _phase("imports done, device set")
     e_full, enc_note = make_log(a, 20221107 + (0 if strong else rank), dev)
+    _phase("headline log generated")
     if strong and world > 1:
         e = take_rows(e_full, shard_episodes(e_full["episode_ids"], rank, world))
     else:
         e = e_full
     pi = synth.dirichlet_policy(a.n_states, a.n_actions)
     seeds = np.arange(R, dtype=np.uint64)
+    want_parity = rank == 0 and not a.no_parity_check and a.shuffle != "table_order"  # (the reference has no unshuffled mode)
+    ora_main = OracleRun(e, pi, a.gamma, [s for s in PARITY_SEEDS if s < R], a.shuffle, 1234, rng=a.rng) if want_parity else None
 
     def barrier():
         if use_pg:
@@ -494,14 +520,17 @@ def run(a):
                 allreduce_estimates(est)  # one RCCL all-reduce of [R,2] f64 (64 KiB at R = 4096), on the device tensor
             return est
 
+        _phase(f"table ingested ({table.N} rows), buffers allocated")
         for _ in range(n_warm):
             one_pass(False)
         barrier()
+        _phase("warm-up passes done")
         t_start = time.perf_counter()
         for _ in range(n_timed):
             est = one_pass(True)
         barrier()
         elapsed = time.perf_counter() - t_start
+        _phase(f"{n_timed} timed passes done")
         el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tot = torch.stack([acc["steps"].sum(), acc["cand"].sum()]).to(torch.float64)
         if use_pg:
@@ -569,16 +598,56 @@ def run(a):
                 "librccl_mapped": any("librccl" in ln for ln in open("/proc/self/maps")),
                 "unchanged_at_one_rank": (bool(torch.equal(m["est"], m["est_local"])) if world == 1 and m["est_local"] is not None else None)}
 
-    def extra_config(name, workload, transitions):
+    def extra_config(name, workload, transitions, subshards=1):
         """One more BASELINE configuration on this GPU, same binary, same R: log generation (host), encoder forward (device), ingest,
-        1 warm-up + 2 timed passes, and its own parity check (the oracle on four seeds of the same table)."""
+        1 warm-up + 2 timed passes, and its own parity check (the oracle on four seeds of the same table).
+        subshards = K > 1: the log is cut into K episode-disjoint parts (shard_episodes, the partition of SURVEY 8(e)) that this GPU
+        evaluates one after the other, all R seeds on each; a pass is the K parts' passes, the per-seed estimate the episode-weighted mean
+        over the parts -- the estimator of the multi-GPU run, one level further down.  Every part has its own oracle parity check."""
         import copy
         b = copy.copy(a)
         b.workload, b.transitions = workload, transitions
         b.encoder = None
+        _phase(f"configuration {name}: start")
         e_c, _ = make_log(b, 20221107, dev)
+        _phase(f"configuration {name}: log generated")
         pi_c = synth.dirichlet_policy(b.n_states, b.n_actions)
-        a_sh, a_rng = a.shuffle, a.rng
+        if subshards > 1:
+            parts = [take_rows(e_c, shard_episodes(e_c["episode_ids"], k, subshards)) for k in range(subshards)]
+            oras = [OracleRun(p, pi_c, a.gamma, [sd for sd in PARITY_SEEDS if sd < R], a.shuffle, 1234) if not a.no_parity_check else None for p in parts]
+            xs = [measure(p, 0, R, 1, 2, False, pi=pi_c, diag=(k == 0)) for k, p in enumerate(parts)]
+            b_c = xs[0]["b_c"] + 4
+            t_scan, t_reset, elapsed = (sum(x[k] for x in xs) for k in ("t_scan", "t_reset", "elapsed"))
+            steps_pass, cand_pass = sum(x["steps_pass"] for x in xs), sum(x["cand_pass"] for x in xs)
+            alg = sum(x["my_cand"] * b_c + x["my_steps"] * x["b_s"] for x in xs)
+            reset_bytes = sum(x["reset_bytes_pass"] for x in xs)
+            out_c = {"workload": f"{workload}, {transitions} transitions x {R} rollouts, nS={b.n_states}, nA={b.n_actions}",
+                     "sharding": f"this GPU's {transitions} rows as {subshards} episode-disjoint parts of {[int(x['rows']) for x in xs]} rows, evaluated one after the "
+                                 f"other, all {R} seeds on each; per-seed estimate = episode-weighted mean over the parts (SURVEY 8(e)'s estimator): states of "
+                                 f"{xs[0]['seg'][1]} rows at most shuffle LDS-resident in stream format A, where the undivided shard's {transitions // b.n_states}-row "
+                                 "states take the chunked shuffle and format C (profiles/r05_bench_c4_shard_12.5M_band1.json: reset 0.88 s, scan 1.17 s)",
+                     "value": steps_pass * 2 / elapsed, "unit": "simulated steps/s", "ms_per_step": elapsed / 2 * 1e3, "scan_s": t_scan / 2, "reset_s": t_reset / 2,
+                     "kernel": xs[0]["variant"], "rollout_tile": xs[0]["tile"], "acceptance": steps_pass / max(cand_pass, 1.0),
+                     "buffer_consumed_frac": cand_pass / (R * transitions), "segment_rows_min_max": [min(x["seg"][0] for x in xs), max(x["seg"][1] for x in xs)],
+                     "roofline": {"bound": "hbm", "achieved": alg * 2 / t_scan / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg * 2 / t_scan / 1e9 / 8000.0,
+                                  "bytes_per_candidate": b_c, "bytes_per_step": xs[0]["b_s"]},
+                     "roofline_reset": {"bound": "hbm", "achieved": reset_bytes * 2 / t_reset / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                        "frac": reset_bytes * 2 / t_reset / 8e12, "bytes_written_per_pass": reset_bytes},
+                     "p_log": xs[0]["plog_dtype"], "queue_orders_resident_bytes": max(x["resident"] for x in xs),
+                     "log_generate_s_host": b.generate_s, "encode_s": b.encode_s, "ingest_s": sum(x["ingest_s"] for x in xs)}
+            if xs[0]["chain"]:
+                out_c["chain"] = xs[0]["chain"]
+            if not a.no_parity_check:
+                _phase(f"configuration {name}: GPU passes done, waiting for the oracle")
+                pcs = [o.check({sd: {k: (float(v[sd]) if k == "sum_g" else int(v[sd])) for k, v in x["acc"].items()} for sd in o.seeds}) for o, x in zip(oras, xs)]
+                _phase(f"configuration {name}: parity checked")
+                out_c["parity_ok"] = all(pc["ok"] for pc in pcs)
+                out_c["parity_max_abs_value_err"] = max(pc["max_abs_value_err"] for pc in pcs)
+                if not out_c["parity_ok"]:
+                    sys.stderr.write(json.dumps(pcs) + "\n")
+                    raise SystemExit(f"bench.py: configuration {name}: the GPU results differ from the oracle on a part of this table -- no number is reported")
+            return out_c
+        ora_c = OracleRun(e_c, pi_c, a.gamma, [sd for sd in PARITY_SEEDS if sd < R], a.shuffle, 1234) if not a.no_parity_check else None
         x = measure(e_c, 0, R, 1, 2, False, pi=pi_c, diag=True)
         b_c = x["b_c"] + 4
         alg = x["my_cand"] * b_c + x["my_steps"] * x["b_s"]
@@ -596,10 +665,11 @@ def run(a):
             out_c["chain"] = x["chain"]
         if getattr(b, "encoder", None):
             out_c["encoder"] = b.encoder
-        if not a.no_parity_check:
-            ps = [sd for sd in PARITY_SEEDS if sd < R]
-            got = {sd: {k: (float(v[sd]) if k == "sum_g" else int(v[sd])) for k, v in x["acc"].items()} for sd in ps}
-            pc = parity_check(oracle_for(e_c), pi_c, a.gamma, ps, got, a_sh, 1234)
+        if ora_c is not None:
+            got = {sd: {k: (float(v[sd]) if k == "sum_g" else int(v[sd])) for k, v in x["acc"].items()} for sd in ora_c.seeds}
+            _phase(f"configuration {name}: GPU passes done, waiting for the oracle")
+            pc = ora_c.check(got)
+            _phase(f"configuration {name}: parity checked")
             out_c["parity_ok"] = pc["ok"]
             out_c["parity_max_abs_value_err"] = pc["max_abs_value_err"]
             if not pc["ok"]:
@@ -610,8 +680,10 @@ def run(a):
     configs = None
     if headline and not a.no_configs:
         configs = {"C2": extra_config("C2", "cartpole", 1_000_000 // test_scale), "C3": extra_config("C3", "grid", 10_000_000 // test_scale),
-                   # one GPU's shard of C4 (100 M transitions over 8 GPUs: 12.5 M rows x all 4096 seeds; stream format C, 5 bytes per position)
-                   "C4_shard": extra_config("C4_shard", "iid", 12_500_000 // test_scale),
+                   # one GPU's shard of C4 (100 M transitions over 8 GPUs: 12.5 M rows x all 4096 seeds), evaluated as two episode-disjoint
+                   # halves (round 6: their ~38 k-row states shuffle LDS-resident; `--workload iid --transitions 12500000` alone is the
+                   # undivided shard: chunked shuffle, stream format C)
+                   "C4_shard": extra_config("C4_shard", "iid", 12_500_000 // test_scale, subshards=2),
                    # one GPU's share of C5 (50 M rows of 128-d fp16 observations over 8 GPUs: 6.25 M rows x 4096 seeds, encoder on MFMA, fp16 p_log)
                    "C5_shard": extra_config("C5_shard", "obs128", 6_250_000 // test_scale)}
 
@@ -661,6 +733,10 @@ def run(a):
                                "bytes_written_per_pass": m["reset_bytes_pass"],
                                "bound_measured": "instruction issue of the single classifier / applier wavefront of each Fisher-Yates chain (LDS-resident; the only HBM traffic is the coalesced write-out)"},
         }
+        if world > 1:
+            out["estimator"] = ("episode-weighted mean over %d shards: per seed (sum of the shards' sum G) / (sum of the shards' completed episodes) -- SURVEY 8(e); "
+                                "NOT the single-table estimate of the N = 1 line (`value_estimate_mean` differs by construction)" % world) if strong else \
+                               ("per seed, the mean over %d independent logs' episodes (weak scaling: one log per GPU)" % world)
         if m["chain"]:
             # why `frac` is what it is: the scan is 4096 exact dependent chains, a chain wavefront retires one accepted step of its four
             # rollouts per iteration, and the kernel lasts (iterations) x (cycles per iteration) / clock -- measured by the kernel's own clock
@@ -680,16 +756,18 @@ def run(a):
         if test_scale > 1:
             out["test_scale"] = test_scale
         base = None
-        if not a.no_parity_check and a.shuffle != "table_order":  # (the reference has no unshuffled mode)
-            base = oracle_for(e)
-            ps = [s for s in PARITY_SEEDS if s < R]
-            got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ps}
-            out["parity_check"] = parity_check(base, pi, a.gamma, ps, got, a.shuffle, 1234, rng=a.rng)
+        if ora_main is not None:
+            got = {s: {k: (float(v[s]) if k == "sum_g" else int(v[s])) for k, v in m["acc"].items()} for s in ora_main.seeds}
+            _phase("headline: waiting for the oracle")
+            out["parity_check"] = ora_main.check(got)
+            _phase("headline: parity checked")
+            base = ora_main.base
             if not out["parity_check"]["ok"]:
                 sys.stderr.write(json.dumps(out["parity_check"]) + "\n")
                 raise SystemExit("bench.py: the GPU results differ from the oracle on this table -- no number is reported")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(base or oracle_for(e), pi, a.gamma, a.cpu_sample_seconds, a.cpu_threads_cap)
+        _phase("CPU baseline done")
         _REAL_STDOUT.write(json.dumps(out) + "\n")
         _REAL_STDOUT.flush()
     if use_pg:

@@ -219,7 +219,7 @@ def test_bench_two_ranks_on_one_device(gpu):
 
 
 def test_philox_stream_provider_against_the_reference_with_a_replayed_stream(gpu):
-    """OFFSIM_STREAM_PHILOX (rocRAND's Philox4x32-10 device API in the generic kernels): the rows the reference's PSRS serves when its
+    """OFFSIM_STREAM_PHILOX in the GENERIC kernels (rocRAND's Philox4x32-10 through its device API): the rows the reference's PSRS serves when its
     rejection_sampling_rng replays the same stream (tests/golden/philox_iid_2k.npz) -- step protocol through
     offsim_step_batch, evalMC through offsim_eval_mc; accepted rows, candidates popped per step, Gs and lengths equal."""
     from rl_offline_simulation_amd import _lib as L
@@ -234,10 +234,11 @@ def test_philox_stream_provider_against_the_reference_with_a_replayed_stream(gpu
     env.reset_sampler(seeds)
     env.set_rejection_seeds(seeds, provider="philox")
     cap = table.N + 1
-    o = env.eval_mc(table.policy_slots(d["pi"]), float(d["gamma"]), ep_cap=table.N0 + 1, trace_cap=cap)
+    # (fast=False: the generic kernel, the literal rocrand_init / rocrand API; since round 6 the default would derive candidate streams
+    # and run the row-packed scan on the same stream -- tests/test_gpu_round6.py)
+    o = env.eval_mc(table.policy_slots(d["pi"]), float(d["gamma"]), ep_cap=table.N0 + 1, trace_cap=cap, fast=False)
     torch.cuda.synchronize()
-    with pytest.raises(L.OffsimError):
-        env.eval_mc(table.policy_slots(d["pi"]), float(d["gamma"]), fast=True)
+    assert o["_kernel"] == "k_eval_mc" and env.scan_variant() != "k_eval_mc_rows"  # (the generic kernel ran; no streams were derived)
     for i, s in enumerate(seeds):
         n = int(o["steps"][i])
         assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), d[f"s{s}_mc_rows"])
