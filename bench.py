@@ -450,6 +450,9 @@ def run(a):
     def measure(e_rank, seed_lo, seed_hi, n_warm, n_timed, fill_full, pi=pi, diag=False):
         """n_warm + n_timed passes of seeds[seed_lo:seed_hi] over the table of e_rank.  Returns the timing, the per-kernel HIP-event
         times and the per-seed results of the last pass."""
+        import gc
+        gc.collect()  # (whatever the configuration before this one left behind -- resident queue orders of up to 250 GB -- goes back to the
+        torch.cuda.empty_cache()  # driver before this one sizes its tile by the free memory)
         torch.cuda.synchronize()
         t_ing = time.perf_counter()
         table = TransitionTable(e_rank["z"], e_rank["actions"], e_rank["rewards"], e_rank["z_next"], e_rank["terminals"],
@@ -567,7 +570,9 @@ def run(a):
                             "top_ups_per_rollout": float((raw[:, 0] >> 32).mean()), "top_ups_late_per_rollout": float(((raw[:, 1] >> 16) & 0xffffff).mean()),
                             "exact_looks_per_rollout": float((raw[:, 1] & 0xffff).mean())}
             _lib.check_async_faults()
-        del envs, table
+        envs.clear()
+        env = o = table = None  # (locals of this frame that still reach the resident buffers)
+        gc.collect()
         torch.cuda.empty_cache()
         return res
 
@@ -737,6 +742,9 @@ def run(a):
             out["estimator"] = ("episode-weighted mean over %d shards: per seed (sum of the shards' sum G) / (sum of the shards' completed episodes) -- SURVEY 8(e); "
                                 "NOT the single-table estimate of the N = 1 line (`value_estimate_mean` differs by construction)" % world) if strong else \
                                ("per seed, the mean over %d independent logs' episodes (weak scaling: one log per GPU)" % world)
+        tb = os.path.join(ROOT, "profiles", "r06_pmc_traffic_breakdown", "traffic_breakdown.json")
+        if traffic and os.path.exists(tb):  # (a claim from committed PMC passes, like `traffic` itself: what the 4 x over-fetch consists of)
+            out["roofline"]["traffic_breakdown"] = json.load(open(tb))
         if m["chain"]:
             # why `frac` is what it is: the scan is 4096 exact dependent chains, a chain wavefront retires one accepted step of its four
             # rollouts per iteration, and the kernel lasts (iterations) x (cycles per iteration) / clock -- measured by the kernel's own clock

@@ -717,7 +717,11 @@ def _workspace_reservation(table, free_b):
     if one <= 0 or max(table.max_seg, table.N0) <= 65536 or os.environ.get("OFFSIM_SHUFFLE_CHUNKED", "1") == "0":
         return 0, False
     budget = max(0, min(int(free_b * 0.92), free_b - (2 << 30)))
-    return min(int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1024)), budget), one <= budget
+    full = int(lib.offsim_shuffle_workspace_bytes(C.byref(table.c), 1024))
+    # A format-C table allocates the workspace FIRST (its format depends on it) and gets what the rule gives; any other table allocates
+    # its stream buffers first and the workspace adapts to what is left (fewer workgroups' pools): a tenth of the free memory is kept
+    # for it, as before round 6 (the full 1024-workgroup reservation cost C3's 2.83 M-row state half its resident rollouts).
+    return (min(full, budget) if stream_format(table) == L.STREAMS_C else min(full, free_b // 10)), one <= budget
 
 
 def rollout_resident_bytes(table, keyed=True, fmt=None):

@@ -47,12 +47,13 @@ assert L.load().offsim_lds_order_ok() == 0
 for N, nS in ((30000, 12), (90000, 1)):   # the second: one state of 90 k rows -- chunked shuffle / stream format C territory
     e = synth.synth_iid(N, nS, 2, seed=N)
     t0 = e["steps"] == 0
-    table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
     pi = synth.dirichlet_policy(nS, 2)
     seeds = [3, 4, 5]
-    env = BatchedPSRS(table, len(seeds))
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
+        # (the guard's one self-test per device runs when the first table is built -- never inside a launch path: round 6)
+        table = TransitionTable(e["z"], e["actions"], e["rewards"], e["z_next"], e["terminals"], e["action_distributions"], t0)
+        env = BatchedPSRS(table, len(seeds))
         env.reset_sampler(seeds, policy=table.policy_slots(pi))
         o = env.eval_mc(table.policy_slots(pi), 0.98, ep_cap=table.N0 + 1)
         torch.cuda.synchronize()

@@ -152,6 +152,39 @@ def test_philox_tests_under_the_other_launch_shapes(variant):
         env["OFFSIM_ROWS_PER_WAVE"] = "2"
     else:
         env.pop("OFFSIM_ROWS_WAVES", None)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "philox and not other_launch_shapes"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "philox and not other_launch_shapes and not bench"],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _bench(args, env_extra=None, timeout=900):
+    import json
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_philox_runs_the_row_packed_scan_with_its_own_parity_check(gpu):
+    """`bench.py --rng philox`: rocRAND's stream in k_eval_mc_rows (not the generic kernel), checked on four seeds against the oracle fed
+    the replayed stream."""
+    out, _ = _bench(["--rng", "philox", "--transitions", "400000", "--rollouts", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert out["config"]["rng"] == "philox" and out["roofline"]["kernel"] == "k_eval_mc_rows"
+    assert out["parity_check"]["ok"] and out["parity_check"]["seeds"] == [0, 1]
+    pcg, _ = _bench(["--transitions", "400000", "--rollouts", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-configs"])
+    assert pcg["parity_check"]["ok"] and pcg["value_estimate_mean"] != out["value_estimate_mean"]  # another sample path
+
+
+@pytest.mark.timeout(900)
+def test_bench_c4_shard_as_two_episode_disjoint_parts_and_the_phase_trace(gpu):
+    """The default line's C4 shard is evaluated as two episode-disjoint halves (each with its own oracle check, run on host threads beside
+    the timed passes); OFFSIM_BENCH_TRACE stamps the command's phases on stderr."""
+    out, err = _bench(["--steps", "1", "--warmup", "0", "--cpu-sample-seconds", "1"], env_extra={"OFFSIM_BENCH_TEST_SCALE": "50", "OFFSIM_BENCH_TRACE": "1"})
+    c4 = out["configs"]["C4_shard"]
+    assert c4["parity_ok"] is True and "2 episode-disjoint parts" in c4["sharding"] and c4["kernel"] == "k_eval_mc_rows"
+    assert c4["segment_rows_min_max"][1] <= 65536 and c4["reset_s"] > 0 and c4["scan_s"] > 0
+    assert "estimator" not in out and out["cpu_baseline"]["value"] > 0 and "the timed passes" in out["parity_check"]["checked"]
+    assert "configuration C4_shard: parity checked" in err and "CPU baseline done" in err
