@@ -67,7 +67,7 @@ def test_philox_in_the_row_packed_scan_against_the_reference_with_a_replayed_str
             assert [int(x) for x in env.state.rng[i].cpu().numpy().view(np.uint64)] == [s, int(pops.sum()), 0, 0]
 
 
-def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed):
+def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed, want_format=None):
     from rl_offline_simulation_amd import synth
     from rl_offline_simulation_amd.table import TransitionTable
     from rl_offline_simulation_amd.evaluators import BatchedPSRS
@@ -89,6 +89,8 @@ def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed):
         o = env.eval_mc(pi, 0.97, ep_cap=64, fast=None if rows else False)
         torch.cuda.synchronize()
         assert ("_kernel" not in o and env.scan_variant() == "k_eval_mc_rows") if rows else True
+        if rows and want_format is not None:
+            assert env._streams["format"] == want_format
         outs.append({k: o[k].cpu().numpy() for k in ("steps", "cand", "n_ep", "n_len", "sum_g", "status", "ep_g", "ep_len")} |
                     {"rng": env.state.rng.cpu().numpy()})
     a, b = outs
@@ -108,6 +110,16 @@ def test_philox_rows_kernel_equals_the_generic_kernel(gpu):
 def test_philox_rows_kernel_from_odd_and_even_stream_positions(gpu):
     """A rollout that was stepped before enters the scan at any stream position: an odd one pairs the draws across Philox blocks."""
     _philox_rows_vs_generic(gpu, 60000, 30, 3, 32, 3, seed=6)
+
+
+@pytest.mark.parametrize("N,pre", [(200000, 0), (300000, 2)])
+def test_philox_rows_kernel_in_stream_formats_c_and_b(N, pre, gpu):
+    """Two states of 100 k rows (stream format C: 14-bit thresholds, written by the chunked shuffle) and of 150 k rows (format B: 16-bit
+    thresholds): the draw's top bits are laid down in the ring at the format's resolution whatever the provider; every count, episode
+    and sum as the generic kernel's (windows run dry all the time on such a table: the exact path and the dry-row handler do the work)."""
+    from rl_offline_simulation_amd import _lib as L
+    a = _philox_rows_vs_generic(gpu, N, 2, 3, 8, pre, seed=7 + pre, want_format=L.STREAMS_C if N == 200000 else L.STREAMS_B)
+    assert a["cand"].min() > 1000
 
 
 def test_philox_against_the_oracle_with_the_same_stream_at_a_million_rows(gpu):
