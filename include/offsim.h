@@ -103,10 +103,10 @@ typedef struct offsim_rollouts {
  *                         sample path, NOT the reference's numbers; its oracle is the reference's own PSRS.step with
  *                         env.rejection_sampling_rng replaced by an object that replays this stream (tests/golden/make_golden.py).
  *                         rng row = seed, draws consumed so far, 0, 0.  Taken by offsim_step_batch, offsim_eval_mc, offsim_eval_td and
- *                         (round 6) by the row-packed scan offsim_eval_mc_streams, whose helper wavefronts fill the draw ring from the
- *                         same engine (rocrand_device::philox4x32_10_engine::ten_rounds, csrc/scan_rows.hpp); the window kernel on
- *                         permutations, offsim_eval_mc_keys, is PCG64-only and returns OFFSIM_EUNSUPPORTED.  In the compiled-policy
- *                         scan a draw is compared as the integer k = u * 2^53 in [1, 2^53] against the 53-bit key; k = 2^53 (u = 1.0
+ *                         (round 6) by both compiled-policy scans, offsim_eval_mc_streams and offsim_eval_mc_keys, which fill their
+ *                         draw rings from the same engine (rocrand_device::philox4x32_10_engine::ten_rounds, csrc/philox_dev.hpp).
+ *                         In the compiled-policy
+ *                         scans a draw is compared as the integer k = u * 2^53 in [1, 2^53] against the 53-bit key; k = 2^53 (u = 1.0
  *                         exactly, probability 2^-53 per draw) is looked at as 2^53 - 1, which differs from the reference's rule only
  *                         against an importance ratio of exactly 1 - 2^-53. */
 #define OFFSIM_STREAM_PCG64 0

@@ -21,7 +21,7 @@
 #include "offsim.h"
 #include "discount.hpp"
 #include "pcg64_dev.hpp"
-#include <rocrand/rocrand_kernel.h>  // device API of Philox4x32-10 (the OFFSIM_STREAM_PHILOX provider)
+#include "philox_dev.hpp"  // rocRAND's Philox4x32-10 on the device (the OFFSIM_STREAM_PHILOX provider)
 
 extern "C" int offsim_lds_order_ok(void);
 #include "shuffle_wave.hpp"
@@ -677,16 +677,6 @@ struct WaveRng {
     int kind;         // OFFSIM_STREAM_*
     uint64_t seed, c; // Philox: the rollout's seed, draws consumed so far (lane k looks at draw c + k)
 };
-
-// Draw i of the Philox provider as the 53-bit integer k with u = k * 2^-53: rocRAND's Philox4x32-10 through its device API, engine
-// (seed, subsequence 0) positioned on 32-bit output 2 i; rocrand_uniform_double of two outputs v1, v2 is
-// 2^-53 + (v1 | (v2 >> 11) << 32) * 2^-53 (rocrand_uniform.h), i.e. k = (v1 | (v2 >> 11) << 32) + 1 in [1, 2^53]: u in (0, 1].
-__device__ __forceinline__ uint64_t philox_k53(uint64_t seed, uint64_t i) {
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(seed, 0ull, 2ull * i, &st);
-    const uint32_t v1 = rocrand(&st), v2 = rocrand(&st);
-    return ((uint64_t)v1 | ((uint64_t)(v2 >> 11) << 32)) + 1ull;
-}
 
 // One PSRS.step (psrs.py:39-51).  All arguments wave-uniform except what lanes load.
 // PROB = double (F64 mode, any p_log type) or float (F32 mode, p_log float).
@@ -1697,7 +1687,7 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     if (!out->sum_g || !out->n_ep || !out->steps || !out->cand || !out->n_len || !out->status)
         return fail(OFFSIM_EINVAL, "eval_mc_keys: required output is NULL%s");
     if (t->n_slots > 256) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: candidate windows support at most 256 states%s");
-    if (ro->rng_kind != OFFSIM_STREAM_PCG64) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: the compiled-policy scans draw from PCG64 only (use offsim_eval_mc)%s");
+    if (ro->rng_kind != OFFSIM_STREAM_PCG64 && ro->rng_kind != OFFSIM_STREAM_PHILOX) return fail(OFFSIM_EINVAL, "eval_mc_keys: unknown stream provider%s");
     if (t->N >= 0xffffffffll) return fail(OFFSIM_EUNSUPPORTED, "eval_mc_keys: queue positions, candidate and step counters are 32-bit (N < 2^32)%s");
     if (n_gamma_pow > 0 && !gamma_pow) return fail(OFFSIM_EINVAL, "eval_mc_keys: gamma_pow is NULL%s");
     if (ro->R == 0) return OFFSIM_OK;
@@ -1705,16 +1695,23 @@ extern "C" int offsim_eval_mc_keys(const offsim_table *t, offsim_rollouts *ro, c
     const int waves = 4;
     dim3 grid((ro->R + waves - 1) / waves), block(waves * 64);
     const bool trace = out->trace_row || out->trace_pop;
+    const bool philox = ro->rng_kind == OFFSIM_STREAM_PHILOX;  // (the provider of the rejection stream is a template parameter, as in the row-packed scan)
     const int rounds = (t->n_slots + 63) / 64;
 #define LAUNCH_WIN(W, ROUNDS)                                                                                         \
     do {                                                                                                              \
         size_t lds = 512 + (((size_t)(t->n_slots + 1) * 4 + 511) & ~(size_t)511) +                                      \
                      (size_t)waves * ((OFFSIM_RING * 4 + (size_t)t->n_slots * (W) * 4 + (size_t)t->n_slots * 16 + OFFSIM_PH * 8 + (trace ? OFFSIM_PH * 4 : 0) + 511) & ~(size_t)511); \
-        if (trace)                                                                                                    \
-            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+        if (trace && philox)                                                                                          \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true, OFFSIM_STREAM_PHILOX>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+        else if (trace)                                                                                               \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, true, OFFSIM_STREAM_PCG64>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+                               n_gamma_pow, max_episodes, *out);                                                      \
+        else if (philox)                                                                                              \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, false, OFFSIM_STREAM_PHILOX>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, false>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
+            hipLaunchKernelGGL((k_eval_mc_win<W, ROUNDS, false, OFFSIM_STREAM_PCG64>), grid, block, lds, st, *t, *ro, keys, gamma, gamma_pow, \
                                n_gamma_pow, max_episodes, *out);                                                      \
     } while (0)
     // window depth by state count so that 16 rollouts (4 blocks) fit one CU's 160 KiB of LDS

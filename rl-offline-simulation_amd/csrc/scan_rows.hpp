@@ -39,6 +39,7 @@
 #include "discount.hpp"
 #include "offsim.h"
 #include "pcg64_dev.hpp"
+#include "philox_dev.hpp"
 #include "scan_win.hpp"  // pack_key / key_T, lds_u32
 #include "shuffle_wave.hpp"  // g_async_fault
 
@@ -224,46 +225,11 @@ __device__ __noinline__ uint64_t rows_exact53(const uint64_t *__restrict__ rng4,
     return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
 }
 
-// ---- the rocRAND provider (OFFSIM_STREAM_PHILOX, include/offsim.h) ----
-// Draw i of a rollout is rocrand_uniform_double of the engine (seed, subsequence 0) positioned on 32-bit output 2 i, i.e. u = k * 2^-53
-// with k = (v1 | (v2 >> 11) << 32) + 1 in [1, 2^53] (philox_k53, offsim_hip.hip).  The compiled keys hold T = the largest 53-bit k with
-// k * 2^-53 <= ratio (psrs.py:55-57 folded by offsim_compile_policy), so "accept iff k <= T" is the reference's rule for every k below
-// 2^53.  The one value beyond the 53 bits of a key, k = 2^53 (u = 1.0 exactly, probability 2^-53 per draw), is looked at as 2^53 - 1:
-// that differs from the rule only against an importance ratio of exactly 1 - 2^-53 (accepted here, rejected there); a ratio >= 1 or NaN
-// (T saturated) accepts both ways.  The generic kernels compare the double itself and have no such corner.
-// The engine itself is rocRAND's: philox4x32_10_engine::ten_rounds (rocrand/rocrand_philox4x32_10.h), reached through a derived class
-// because the public rocrand_init / rocrand pair indexes the engine's state by a run-time sub-position (private memory: scratch
-// loads in the helper's loop).  Key and counter are set as rocrand_init(seed, 0, 4 m) sets them -- key = the seed's two halves,
-// counter = m -- so block(seed, m) is the four 32-bit outputs 4 m .. 4 m + 3 of that engine, i.e. draws 2 m and 2 m + 1
-// (tests/test_gpu_round6.py holds it against philox_k53, the literal API, through the generic kernel and the reference's replayed stream).
-struct RowsPhilox : rocrand_device::philox4x32_10_engine {
-    __device__ __forceinline__ RowsPhilox() {}
-    __device__ __forceinline__ uint4 block(uint64_t seed, uint64_t m) {
-        const uint2 key = {(unsigned int)seed, (unsigned int)(seed >> 32)};
-        const uint4 ctr = {(unsigned int)m, (unsigned int)(m >> 32), 0u, 0u};
-        return this->ten_rounds(ctr, key);
-    }
-};
-__device__ __forceinline__ uint64_t rows_philox_clamp(uint32_t v1, uint32_t v2) {
-    const uint64_t k = ((uint64_t)v1 | ((uint64_t)(v2 >> 11) << 32)) + 1ull;
-    return k > 0x1fffffffffffffull ? 0x1fffffffffffffull : k;
-}
-// both draws of one Philox block: draws 2 m and 2 m + 1
-__device__ __forceinline__ void rows_philox_pair(uint64_t seed, uint64_t m, uint64_t &k0, uint64_t &k1) {
-    RowsPhilox e;
-    const uint4 v = e.block(seed, m);
-    k0 = rows_philox_clamp(v.x, v.y);
-    k1 = rows_philox_clamp(v.z, v.w);
-}
-__device__ __forceinline__ uint64_t rows_philox_k(uint64_t seed, uint64_t i) {
-    uint64_t k0, k1;
-    rows_philox_pair(seed, i >> 1, k0, k1);
-    return (i & 1ull) ? k1 : k0;
-}
+// ---- the rocRAND provider (OFFSIM_STREAM_PHILOX): csrc/philox_dev.hpp ----
 // the exact look's draw, by provider: index = draws of the stream before it
 template <int RNG>
 __device__ __forceinline__ uint64_t rows_exact_draw(const uint64_t *__restrict__ rng4, uint64_t index) {
-    if constexpr (RNG == OFFSIM_STREAM_PHILOX) return rows_philox_k(rng4[0], rng4[1] + index);
+    if constexpr (RNG == OFFSIM_STREAM_PHILOX) return offsim_philox_k(rng4[0], rng4[1] + index);
     else return rows_exact53(rng4, index + 1u);
 }
 
@@ -383,10 +349,10 @@ __global__ void __launch_bounds__(HELPER ? 512 : 256)
             const uint64_t d0 = ph_c0 + (uint64_t)gen + 2u * (li & 7u);
             uint64_t k0, k1;
             if ((ph_c0 & 1ull) == 0ull) {
-                rows_philox_pair(ph_seed, d0 >> 1, k0, k1);
+                offsim_philox_pair(ph_seed, d0 >> 1, k0, k1);
             } else {
-                k0 = rows_philox_k(ph_seed, d0);
-                k1 = rows_philox_k(ph_seed, d0 + 1ull);
+                k0 = offsim_philox_k(ph_seed, d0);
+                k1 = offsim_philox_k(ph_seed, d0 + 1ull);
             }
             const uint32_t low = (1u << F.tshift) - 1u;
             const scan_u32x2 pr = {(uint32_t)(k0 >> 21) | low, (uint32_t)(k1 >> 21) | low};

@@ -21,6 +21,7 @@
 #include "discount.hpp"
 #include "offsim.h"
 #include "pcg64_dev.hpp"
+#include "philox_dev.hpp"
 
 namespace offsim {
 
@@ -99,7 +100,10 @@ __device__ __forceinline__ void wr_lane(uint32_t (&v)[ROUNDS], int q, int l, uin
 // (ballot masks, the draw counter, the current state) stays scalar.
 //
 // LDS per block: [seg_off (n_slots+1) u32, shared] then per wave [win n_slots*W u32][ring 128 u32][meta n_slots x {cur, landed}]
-template <int W, int ROUNDS, bool TRACE>
+// RNG (round 6): the provider of the rejection stream, as in the row-packed scan (OFFSIM_STREAM_PCG64: NumPy's default_rng, the
+// reference's numbers; OFFSIM_STREAM_PHILOX: rocRAND's Philox4x32-10, csrc/philox_dev.hpp) -- the ring's fill, the exact look's draw
+// and the stream state written back are all that differ.
+template <int W, int ROUNDS, bool TRACE, int RNG = OFFSIM_STREAM_PCG64>
 __global__ void __launch_bounds__(256, 4)
     k_eval_mc_win(offsim_table t, offsim_rollouts ro, const uint64_t *__restrict__ keys, double gamma,
                   const double *__restrict__ gamma_pow, int64_t n_gamma_pow64, int64_t max_episodes64, offsim_evalmc_out out) {
@@ -177,9 +181,13 @@ __global__ void __launch_bounds__(256, 4)
     for (int e = 0; e < D; e++) idxA[e] = digB[e] = 0;
 
     // ---- rejection stream: ring of the top 21 bits of the next draws ----
-    U128 lane_state;
+    constexpr bool philox = RNG == OFFSIM_STREAM_PHILOX;
+    U128 lane_state = u128(0, 0);
     Jump j64;
-    {
+    j64.mult = u128(0, 1);
+    j64.plus = u128(0, 0);
+    const uint64_t ph_seed = philox ? ro.rng[4 * r + 0] : 0ull, ph_c0 = philox ? ro.rng[4 * r + 1] : 0ull;  // Philox: (seed, draws consumed so far, 0, 0)
+    if (!philox) {
         const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
         const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
         j64 = pcg_jump(inc, 64);
@@ -187,16 +195,36 @@ __global__ void __launch_bounds__(256, 4)
     }
     uint32_t gen = 0, c = 0;  // draws generated / consumed since kernel start (every examined candidate = one draw)
     auto gen_block = [&]() {
-        ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43) << 11;  // top 21 bits, aligned with the digest's T21
-        lane_state = pcg_apply(j64, lane_state);
+        if constexpr (philox) {
+            // lanes 0..31 each own one block = two draws (lanes 32..63 repeat them); a stream position of odd parity pairs the draws
+            // across blocks: every lane then works out its two draws one by one (a rollout that was stepped before: rare)
+            const uint64_t d0 = ph_c0 + (uint64_t)gen + 2u * ((uint32_t)lane & 31u);
+            uint64_t k0, k1;
+            if ((ph_c0 & 1ull) == 0ull) {
+                offsim_philox_pair(ph_seed, d0 >> 1, k0, k1);
+            } else {
+                k0 = offsim_philox_k(ph_seed, d0);
+                k1 = offsim_philox_k(ph_seed, d0 + 1ull);
+            }
+            const uint32_t at = (gen + 2u * ((uint32_t)lane & 31u)) & (OFFSIM_RING - 1);  // (gen is a multiple of 64: the pair never wraps)
+            ring[at] = (uint32_t)(k0 >> 32) << 11;  // top 21 bits of the 53-bit draw, aligned with the digest's T21
+            ring[at + 1u] = (uint32_t)(k1 >> 32) << 11;
+        } else {
+            ring[(gen + lane) & (OFFSIM_RING - 1)] = (uint32_t)(pcg_output(lane_state) >> 43) << 11;  // top 21 bits, aligned with the digest's T21
+            lane_state = pcg_apply(j64, lane_state);
+        }
         gen += 64;
     };
     gen_block();
     gen_block();
-    auto exact53 = [&](uint32_t n_steps) -> uint64_t {  // k53 of the draw that needs n_steps LCG steps from the start
-        const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
-        const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
-        return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
+    auto exact53 = [&](uint32_t n_steps) -> uint64_t {  // the 53-bit draw that is the n_steps-th of this launch (n_steps >= 1)
+        if constexpr (philox) {
+            return offsim_philox_k(ph_seed, ph_c0 + (uint64_t)n_steps - 1ull);
+        } else {
+            const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
+            const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
+            return pcg_output(pcg_apply(pcg_jump(inc, n_steps), base)) >> 11;
+        }
     };
 
     // ---- initial-state prefetch: lane i holds the slot of init index ib+i ----
@@ -571,7 +599,9 @@ __global__ void __launch_bounds__(256, 4)
     if (lane == 0) {
         ro.init_cursor[r] = ic;
         ro.cur_slot[r] = slot;
-        if (c) {
+        if (c && philox) {
+            ro.rng[4 * r + 1] = ph_c0 + c;  // (seed, draws consumed so far, 0, 0)
+        } else if (c) {
             const U128 base = u128(ro.rng[4 * r + 0], ro.rng[4 * r + 1]);
             const U128 inc = u128(ro.rng[4 * r + 2], ro.rng[4 * r + 3]);
             U128 nb = pcg_apply(pcg_jump(inc, c), base);

@@ -116,8 +116,7 @@ class BatchedPSRS:
         (step / step_single / eval_td / the generic eval_mc need permutations and rebuild them from the streams on first use.)
         `rejection`: the provider of the rejection stream the rollouts start with -- "pcg64" = default_rng(seed) (psrs.py:20, the
         reference's numbers) or "philox" = rocRAND's Philox4x32-10 of the same seeds (set_rejection_seeds; the queue orders stay
-        NumPy's).  With "philox" the candidate streams are written whenever the row-packed scan can take the table at all: the
-        window kernel, which the speed rule of _streams_apply would otherwise prefer for some tables, draws from PCG64 only."""
+        NumPy's).  Every scan takes either provider; which scan a table gets does not depend on it."""
         if rejection not in ("pcg64", "philox"):
             raise ValueError(rejection)
         self._quiesce()
@@ -130,7 +129,7 @@ class BatchedPSRS:
         self.state.rewind()
         self._streams = None
         self._perm_lazy = None
-        keyed = policy is not None and self._streams_apply(policy, whenever_able=rejection == "philox")
+        keyed = policy is not None and self._streams_apply(policy)
         if shuffle == SHUFFLE_PER_ROLLOUT:
             if self._init_perm_buf is None or self._init_perm_buf.shape[0] != self.R:
                 self._init_perm_buf = torch.empty((self.R, max(t.N0, 1)), dtype=torch.int32, device=dev)
@@ -215,7 +214,7 @@ class BatchedPSRS:
         return self._ws
 
     # ---- candidate streams for the row-packed scan ----
-    def _streams_apply(self, policy, whenever_able=False):
+    def _streams_apply(self, policy):
         """Whether the candidate streams and the row-packed scan serve `policy` on this table: what offsim_eval_mc_streams covers (f64
         probabilities, the default reject rule, <= 256 states, states of up to 2^23 rows), and -- unless OFFSIM_SCAN_ROWS forces it --
         where that kernel is the faster one (below)."""
@@ -238,7 +237,7 @@ class BatchedPSRS:
         ok = (f64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= (256 if t.max_seg <= 65536 else 255) and 0 < t.max_seg <= (1 << 23)
               and t.N < 2 ** 32 - 1 and mode != "0")  # (formats B and C: 255 states)
         ok = ok and L.lds_order_ok(t.device)  # (runtime guard of the tick's lane-ordered LDS atomic; never forced past)
-        if not ok or mode == "1" or whenever_able:
+        if not ok or mode == "1":
             return ok
         # Round 5 (tools/diag_scan.py, profiles/r05_diag_scan_c2_c3_c5.txt): L says nothing about a window that is FULL and still gives no
         # clear accept -- eight entries are all rejected with probability (1 - acceptance)^8: 0.2 % of the looks at 0.54, 6.5 % at
@@ -316,7 +315,7 @@ class BatchedPSRS:
         """Candidate streams from queue orders that exist as permutations (reset_sampler without `policy`): one gather, done
         for jobs of up to `max_entries` queue positions; bigger jobs pass `policy` to reset_sampler or run the window kernels."""
         t, st = self.table, self.state
-        if not self._streams_apply(policy, whenever_able=st.rng_kind == L.STREAM_PHILOX) or (st.perm is None and self._perm_lazy == "streams"):
+        if not self._streams_apply(policy) or (st.perm is None and self._perm_lazy == "streams"):
             return
         n_rows = 1 if (st.perm is None or st.perm_stride == 0) else self.R
         if n_rows * t.N > max_entries:
@@ -381,9 +380,9 @@ class BatchedPSRS:
     def set_rejection_seeds(self, seeds, provider="pcg64"):
         """Replace only the rejection streams (env.rejection_sampling_rng = ..., psrs.py:20 is a plain attribute).
         provider = "pcg64": default_rng(seed) -- the reference's numbers.  provider = "philox": rocRAND's Philox4x32-10 through its
-        device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by step / step_single / eval_td,
-        the generic eval_mc and the row-packed scan on candidate streams (the window kernel on permutations draws from PCG64 only);
-        reset_sampler puts PCG64 back unless it is told rejection="philox"."""
+        device API (include/offsim.h OFFSIM_STREAM_PHILOX): another, equally valid sample path, taken by every kernel (step /
+        step_single / eval_td, the generic eval_mc, the row-packed scan and the window kernel); reset_sampler puts PCG64 back unless it
+        is told rejection="philox"."""
         self._quiesce()
         sd = seeds.to(self.table.device) if isinstance(seeds, torch.Tensor) else seeds_tensor(seeds, self.table.device)
         assert sd.numel() == self.R, "one seed per rollout"
@@ -599,8 +598,7 @@ class BatchedPSRS:
                          n_len=L.ptr(o["n_len"]), status=L.ptr(o["status"]), ep_g=L.ptr(o.get("ep_g")),
                          ep_len=L.ptr(o.get("ep_len")), ep_cap=ep_cap, trace_row=L.ptr(o.get("trace_row")),
                          trace_pop=L.ptr(o.get("trace_pop")), trace_cap=trace_cap)
-        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256
-        philox = self.state.rng_kind == L.STREAM_PHILOX
+        can_fast = mode == L.PROB_F64 and self.reject_mode == L.REJECT_DEFAULT and t.n_slots <= 256  # (either stream provider)
         if fast is None:
             fast = can_fast
         if fast and not can_fast:
@@ -620,14 +618,6 @@ class BatchedPSRS:
             L.check(L.load().offsim_eval_mc_streams(C.byref(t.c), C.byref(self.state.c), C.byref(smc), L.ptr(keys), float(gamma), L.ptr(gp),
                                                     gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
             o["_keepalive"] = (pi_d, gp, keys, sm)
-        elif fast and philox:
-            # the rocRAND provider runs in the row-packed scan (candidate streams: reset_sampler(policy=..., rejection="philox"), or
-            # orders small enough to derive them from) and in the generic kernel; the window kernel on permutations draws from PCG64 only
-            self._orders_for_generic()
-            L.check(L.load().offsim_eval_mc(C.byref(t.c), C.byref(self.state.c), L.ptr(pi_d), mode, self.reject_mode, float(gamma),
-                                            L.ptr(gp), gp.numel(), int(n_episodes), C.byref(oc), L.stream_ptr()))
-            o["_keepalive"] = (pi_d, gp)
-            o["_kernel"] = "k_eval_mc"
         elif fast:
             keys = self.compile_policy(pi_d)
             L.check(L.load().offsim_eval_mc_keys(C.byref(t.c), C.byref(self.state.c), L.ptr(keys), float(gamma), L.ptr(gp),

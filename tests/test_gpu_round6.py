@@ -67,7 +67,45 @@ def test_philox_in_the_row_packed_scan_against_the_reference_with_a_replayed_str
             assert [int(x) for x in env.state.rng[i].cpu().numpy().view(np.uint64)] == [s, int(pops.sum()), 0, 0]
 
 
-def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed, want_format=None):
+@pytest.mark.parametrize("name", ["philox_iid_2k", "philox_iid_50k"])
+def test_philox_in_the_window_kernel_against_the_reference_with_a_replayed_stream(name, gpu, monkeypatch):
+    """The same fixtures through csrc/scan_win.hpp on permutations (OFFSIM_SCAN_ROWS=0: the scan a table with a hot state gets), whose
+    ring is filled from the same engine: k_eval_mc_win<.., OFFSIM_STREAM_PHILOX>, traced and untraced."""
+    from rl_offline_simulation_amd.evaluators import BatchedPSRS
+    monkeypatch.setenv("OFFSIM_SCAN_ROWS", "0")
+    d = load(name)
+    table = _table(d, gpu)
+    seeds = [int(s) for s in d["seeds"]]
+    pi = table.policy_slots(d["pi"])
+    env = BatchedPSRS(table, len(seeds))
+    for traced in (True, False):
+        env.reset_sampler(seeds, policy=pi, rejection="philox")
+        assert env._streams is None and env.scan_variant().startswith("k_eval_mc_win")
+        o = env.eval_mc(pi, float(d["gamma"]), ep_cap=table.N0 + 1, trace_cap=(table.N + 1) if traced else 0)
+        torch.cuda.synchronize()
+        assert "_kernel" not in o
+        for i, s in enumerate(seeds):
+            rows, pops = d[f"s{s}_mc_rows"], d[f"s{s}_mc_popped"]
+            n = int(o["steps"][i])
+            assert n == len(rows) and int(o["cand"][i]) == int(pops.sum()), (s, traced)
+            if traced:
+                assert np.array_equal(o["trace_row"][i, :n].cpu().numpy(), rows)
+                assert np.array_equal(o["trace_pop"][i, :n].cpu().numpy(), pops[:n])
+            ne, nl = int(o["n_ep"][i]), int(o["n_len"][i])
+            assert np.array_equal(o["ep_g"][i, :ne].cpu().numpy(), d[f"s{s}_mc_Gs"])
+            assert np.array_equal(o["ep_len"][i, :nl].cpu().numpy(), d[f"s{s}_mc_lengths"])
+            assert [int(x) for x in env.state.rng[i].cpu().numpy().view(np.uint64)] == [s, int(pops.sum()), 0, 0]
+
+
+def test_philox_window_kernel_equals_the_generic_kernel_from_either_parity(gpu, monkeypatch):
+    """k_eval_mc_win under Philox against k_eval_mc (the literal rocrand_init / rocrand API) on a 100 k-row table with a hot state, the
+    rollouts entering the scan at stream positions of either parity."""
+    monkeypatch.setenv("OFFSIM_SCAN_ROWS", "0")
+    a = _philox_rows_vs_generic(gpu, 100000, 40, 3, 32, 3, seed=9, kernel="win")
+    assert a["steps"].min() > 100
+
+
+def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed, want_format=None, kernel="rows"):
     from rl_offline_simulation_amd import synth
     from rl_offline_simulation_amd.table import TransitionTable
     from rl_offline_simulation_amd.evaluators import BatchedPSRS
@@ -88,7 +126,7 @@ def _philox_rows_vs_generic(gpu, N, nS, nA, R, pre_steps, seed, want_format=None
             assert len(set((env.state.rng[:, 1].cpu().numpy() & 1).tolist())) == 2
         o = env.eval_mc(pi, 0.97, ep_cap=64, fast=None if rows else False)
         torch.cuda.synchronize()
-        assert ("_kernel" not in o and env.scan_variant() == "k_eval_mc_rows") if rows else True
+        assert ("_kernel" not in o and env.scan_variant() == ("k_eval_mc_rows" if kernel == "rows" else "k_eval_mc_win")) if rows else True
         if rows and want_format is not None:
             assert env._streams["format"] == want_format
         outs.append({k: o[k].cpu().numpy() for k in ("steps", "cand", "n_ep", "n_len", "sum_g", "status", "ep_g", "ep_len")} |
